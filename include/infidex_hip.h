@@ -1,0 +1,178 @@
+/*
+ * infidex_hip.h — C ABI of libinfidex_hip.so: the MI355X (gfx950) drop-in for the query-time scoring hot path
+ * of lofcz/Infidex (SearchEngine.Search -> SearchPipeline.Execute).
+ *
+ * The reference has no FFI seam today; the two INTERNAL calls this library replaces are
+ *   S1  Bm25Scorer.Search(TermScoreInfo[] termInfos, int topK, int totalDocs, float[] docLengths, float avgdl, ...)
+ *         -> TopKHeap                       src/Infidex/Indexing/Bm25Scorer.cs:56-67  (caller VectorModel.cs:567-569)
+ *   S2  CoverageEngine.CalculateFeatures(ctx, docText, lcsSum, buffer, docId) + FusionScorer.Calculate(...)
+ *         -> (float score, byte tiebreaker) src/Infidex/Coverage/CoverageEngine.cs:174, Scoring/FusionScorer.cs:19-25
+ *                                           (caller SearchPipeline.ProcessCandidate, Scoring/SearchPipeline.cs:449-522)
+ * A C# host binds these entry points with [DllImport("infidex_hip")] (stub in INTEGRATION.md).
+ *
+ * Conventions: every function returns an int32 status (0 = INFX_OK); no exceptions cross the ABI; the caller owns
+ * all buffers; uploads are copied to HBM and host pointers are never retained; handles are opaque and freed only by
+ * infx_destroy. infx_stage*_batch are re-entrant on an uploaded (immutable) index when each caller uses its own
+ * infx_stream; infx_upload_* / infx_destroy are exclusive (the reference holds its write lock there,
+ * SearchEngine.cs:96-104). Thread-local error text: infx_last_error().
+ */
+#ifndef INFIDEX_HIP_H
+#define INFIDEX_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INFX_OK            0
+#define INFX_EINVAL        1   /* bad argument / unsupported size */
+#define INFX_ENOMEM        2   /* hipMalloc failed */
+#define INFX_EHIP          3   /* HIP runtime error (incl. "no GPU") */
+#define INFX_ECAPACITY     4   /* a per-batch workspace bound would be exceeded; split the batch */
+#define INFX_EUNSUPPORTED  5   /* input outside the supported envelope (e.g. > INFX_MAX_DOC_TOKENS tokens) */
+
+#define INFX_MAX_QUERY_TERMS   128  /* VectorModel.cs:381 rents 128 raw tokens */
+#define INFX_MAX_QUERY_TOKENS  32   /* Stage-2 query words after dedupe */
+#define INFX_MAX_QUERY_CHARS   256
+#define INFX_MAX_DOC_TOKENS    192  /* Stage-2 words per document text */
+#define INFX_NFEAT             32   /* ints per infx_cov_out.feat */
+
+typedef struct infx_index infx_index;     /* device-resident immutable index (one shard) */
+typedef struct infx_stream infx_stream;   /* per-caller HIP stream + workspace */
+
+/* Replaces the constants of Bm25Scorer.cs:21-23 / ConfigurationParameters.cs:101-104. */
+typedef struct infx_config {
+    int32_t device;          /* HIP device ordinal */
+    int32_t range_docs;      /* documents per LDS range block (power of two, 512..8192); 0 = default 2048 */
+    int32_t max_depth;       /* largest Query.CoverageDepth that will be used (default 500) */
+    int32_t reserved;
+} infx_config;
+
+int32_t infx_create(const infx_config* cfg, infx_index** out);
+void    infx_destroy(infx_index* idx);
+const char* infx_last_error(void);
+
+/* Postings: Term.docIds/weights (Core/Term.cs:21-22) flattened to CSR. df[t] < 0 marks a stop term (Term.cs:134-146);
+ * its slice must be empty. doc ids are shard-local internal ids in ascending order. */
+int32_t infx_upload_postings(infx_index* idx, uint32_t num_terms, const uint64_t* offs /* T+1 */,
+                             const int32_t* doc_ids, const uint8_t* tf, const int32_t* df);
+
+/* Documents: VectorModel._docLengths/_avgDocLength (VectorModel.cs:25-26, global avgdl!), DocumentKey, and the
+ * Stage-2 text = ToLowerInvariant(TextNormalizer.Normalize(doc.IndexedText)) as UTF-16 (SegmentProcessor.cs:42-75;
+ * every Stage-2 comparison in the reference is OrdinalIgnoreCase, so folding once at upload is equivalent). */
+int32_t infx_upload_docs(infx_index* idx, uint32_t num_docs, const float* doc_len, float avgdl,
+                         const int64_t* doc_key, const uint64_t* text_offs /* N+1 */, const uint16_t* text_utf16);
+
+/* Prefix DocSets (PrefixPostingList.DocSet, Indexing/ShortQuery/PrefixPosting.cs:64,109-137) that prefix precedence
+ * can accept (population <= 20*max_depth), CSR over sets; referenced by set index from infx_query.prefix_set. */
+int32_t infx_upload_prefix_docsets(infx_index* idx, uint32_t num_sets, const uint64_t* offs, const int32_t* doc_ids);
+
+/* Document-sharded operation: this index holds internal ids [doc_base, doc_base+num_docs) of a corpus
+ * of total_docs; corpus statistics passed in queries are global. */
+int32_t infx_set_shard(infx_index* idx, int32_t rank, int32_t nranks, int32_t doc_base, int32_t total_docs);
+
+int32_t infx_stream_create(infx_index* idx, infx_stream** out);
+void    infx_stream_destroy(infx_stream* s);
+
+/* ---- Stage 1 ------------------------------------------------------------------------------------------------- */
+/* One term of a query, in Bm25Scorer order (ascending termId; fuzzy virtual terms first — VectorModel.cs:442). */
+typedef struct infx_term {
+    int32_t  term_id;      /* >= 0: index term; -1: virtual (fuzzy-union) term, postings in the batch's extra arrays */
+    uint32_t extra_off;    /* virtual term: offset into infx_stage1_batch.extra_docs; its tf == 1 (RoaringPostingsEnum.cs:21) */
+    uint32_t extra_len;
+    float    idf;          /* Bm25Scorer.ComputeIdf on the host (MathF.Log), Bm25Scorer.cs:686-695 */
+    float    max_score;    /* VectorModel.cs:525-531 */
+    uint8_t  role;         /* INFX_ROLE_* bits: membership in the candidate tiers */
+    uint8_t  rank;         /* disjunctive: position in the IDF-descending order among eligible terms (TieredCandidateSelector.cs:253) */
+    uint16_t reserved;
+} infx_term;
+
+#define INFX_ROLE_AND      1   /* AND mode: member of terms[0..n-2] (everything but the lowest-IDF term) */
+#define INFX_ROLE_LOWEST   2   /* AND mode: the lowest-IDF term (dropped by Tier 1)                      */
+#define INFX_ROLE_S1       4   /* AND mode: first selective term of Tier 2                               */
+#define INFX_ROLE_S2       8   /* AND mode: second selective term of Tier 2                              */
+#define INFX_ROLE_ELIGIBLE 16  /* disjunctive: not low-quality (idf >= 0.2*maxIdf)                       */
+#define INFX_ROLE_LOWQ     32  /* disjunctive: low-quality term (only used when nothing selective hit)   */
+
+#define INFX_MODE_PREFIX   1   /* candidates = accepted prefix DocSet alone (TieredCandidateSelector.cs:66-82)   */
+#define INFX_MODE_DISJ     2   /* SelectCandidatesDisjunctive (:108-125, :243-322)                               */
+#define INFX_MODE_AND      3   /* Tier 0/1/2 (:128-234)                                                          */
+
+typedef struct infx_query {
+    uint32_t term_off;     /* into the batch's terms[] */
+    uint32_t num_terms;
+    int32_t  mode;         /* INFX_MODE_* (decided on the host from global df / DocSet populations) */
+    int32_t  prefix_set;   /* MODE_PREFIX: the candidate set; other modes: set of pre-"seen" docs (< min(2k,100) docs) or -1 */
+    int32_t  depth;        /* topK handed to Bm25Scorer.Search == Query.CoverageDepth (SearchPipeline.cs:282) */
+    int32_t  n_and;        /* AND mode: number of terms (n); needed for the Tier-0 / Tier-1 membership tests */
+    int32_t  df_s1;        /* AND mode: global df of S1 / S2 (Tier-2 cardinality tests, :221) */
+    int32_t  df_s2;
+} infx_query;
+
+typedef struct infx_hit { int32_t doc; float score; } infx_hit;   /* doc = global internal id; key via infx_upload_docs */
+
+/* Per-query class counts of the candidate tiers on THIS shard (sum over shards before infx_stage1_select when sharded). */
+#define INFX_NCLASS 136
+typedef struct infx_counts { uint32_t c[INFX_NCLASS]; } infx_counts;
+
+/* Stage 1a: stream postings, accumulate BM25+ in LDS, emit candidate supersets + class counts (device resident). */
+int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
+                               uint32_t extra_n, const int32_t* extra_docs, infx_counts* counts_out /* nq, host */);
+/* Stage 1b: apply the tier rules with (global) counts, select the top-`depth` per query ordered by
+ * (score desc, DocumentKey asc). out: nq*depth hits; out_count: nq. Replaces UpdateTopK/PriorityQueue (Bm25Scorer.cs:654-670). */
+int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* counts /* nq, host, global */,
+                           infx_hit* out, uint32_t* out_count);
+/* Convenience for the unsharded case: accumulate + select. == Bm25Scorer.Search for a batch of queries. */
+int32_t infx_stage1_batch(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
+                          uint32_t extra_n, const int32_t* extra_docs, infx_hit* out, uint32_t* out_count);
+
+/* ---- Stage 2 ------------------------------------------------------------------------------------------------- */
+/* CoverageQueryContext (Coverage/CoverageEngine.cs:9-43) of one query, prepared on the host (PrepareQuery :61-126). */
+typedef struct infx_cov_query {
+    uint16_t text[INFX_MAX_QUERY_CHARS];          /* normalised, lower-cased query */
+    int32_t  text_len;
+    int32_t  num_tokens;                          /* deduplicated, MinWordSize-filtered */
+    uint16_t tok_off[INFX_MAX_QUERY_TOKENS];
+    uint16_t tok_len[INFX_MAX_QUERY_TOKENS];
+    float    term_idf[INFX_MAX_QUERY_TOKENS];     /* n-gram averaged (ComputeTermIdf :388-427) */
+    float    word_idf[INFX_MAX_QUERY_TOKENS];     /* WordIdfCache (VectorModel.cs:864-908), 0 when absent */
+    int32_t  has_word_idf;
+    int32_t  num_fusion_tokens;                   /* unfiltered tokens (minWordSize 0), CoverageEngine.cs:348-352 */
+    uint16_t ftok_off[INFX_MAX_QUERY_TOKENS * 2];
+    uint16_t ftok_len[INFX_MAX_QUERY_TOKENS * 2];
+    int32_t  lcs_tolerance;                       /* SearchPipeline.cs:498-500 */
+    int32_t  reserved;
+} infx_cov_query;
+
+typedef struct infx_cov_cand {
+    uint32_t query;        /* index into the batch's infx_cov_query[] */
+    int32_t  doc;          /* shard-local internal id */
+    float    base_score;   /* normBm25 = s / s_top1, or 0 for WordMatcher candidates (SearchPipeline.cs:380-414) */
+    int32_t  want_lcs;     /* 1 for docIndex < 2 (quirk Q7, SearchPipeline.cs:492-503) */
+} infx_cov_cand;
+
+typedef struct infx_cov_out {
+    float   score;         /* FusionScorer.Calculate: (float)precedence + semantic */
+    uint8_t tiebreaker;
+    uint8_t word_hits;     /* min(WordHits,255) */
+    uint8_t lcs;           /* min(lcs,255) when want_lcs */
+    uint8_t status;        /* 0 ok, INFX_EUNSUPPORTED when the text exceeds INFX_MAX_DOC_TOKENS */
+    int32_t word_hits_full;
+    int32_t feat[INFX_NFEAT];   /* CoverageFeatures / FusionSignals ints (bit-exact parity target), layout in DESIGN.md */
+} infx_cov_out;
+
+int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, uint32_t ncand,
+                          const infx_cov_cand* cand, infx_cov_out* out, int32_t want_features);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------ */
+/* Durations (ms) of the last Stage-1 accumulate / select / Stage-2 launches on this stream, from HIP events recorded on
+ * the stream the kernels ran on. */
+int32_t infx_last_timings(infx_stream* s, float* accumulate_ms, float* select_ms, float* stage2_ms);
+/* Algorithmic bytes of the last accumulate launch: sum over (query, term) of posting bytes actually streamed
+ * (5 B/posting, 4 B for virtual terms) + 4 B per emitted candidate norm gather + 8 B per emitted hit. */
+int32_t infx_last_alg_bytes(infx_stream* s, uint64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,841 @@
+// libinfidex_hip.so — device side + C ABI (include/infidex_hip.h). gfx950 (MI355X) only.
+//
+// Replaces, for a BATCH of queries on a device-resident index shard:
+//   Bm25Scorer.Search + TieredCandidateSelector.SelectCandidates   (Indexing/Bm25Scorer.cs:56-193,
+//        Scoring/TieredCandidateSelector.cs:53-237)        -> k_accumulate + k_select
+//   CoverageEngine.CalculateFeatures + FusionScorer.Calculate      (Coverage/CoverageEngine.cs:174-382,
+//        Scoring/FusionScorer.cs:19-236)                    -> k_stage2   (stage2.hip.inc)
+//
+// Stage-1 design (HBM-bound integer/byte streaming, no MFMA): the doc-id space is cut into ranges of R docs. One
+// wave (= one 64-thread workgroup) owns one (query, range): the fp32 partial scores and the tier flags of the R docs
+// live in LDS; every posting list of the query is read exactly once, coalesced, from the slice that falls in the
+// range (located through a per-term range skip table); a wave executes its LDS read-modify-writes in program order, so
+// the per-document accumulation order is the reference's term order with no barriers and no atomics. Candidate tiers
+// (quirk Q11) are evaluated from per-doc flags; a range that holds no candidate-generating posting exits before it
+// streams anything else (range-granular WAND skip). Survivors are compacted with wave ballots into a batch arena and
+// k_select picks the top-`depth` per query with an LDS radix select + bitonic sort.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <mutex>
+#include "../../include/infidex_hip.h"
+
+#define WAVE 64
+
+static thread_local std::string g_err;
+static int32_t fail(int32_t code, const char* fmt, const char* a = "") {
+    char buf[512]; snprintf(buf, sizeof buf, fmt, a); g_err = buf; return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(INFX_EHIP, #x ": %s", hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+struct DevIndex {
+    int32_t N, T, R, rshift, nRanges, docBase, totalDocs;
+    const uint64_t* postOff; const int32_t* postDoc; const uint8_t* postW;
+    const float* docNorm;      // K1*((1-B) + (B/avgdl)*dl) — the 8-lane formula of Bm25Scorer.cs:413-416
+    const int64_t* docKey;
+    const uint64_t* textOff; const uint16_t* text;
+    const uint32_t* skipIdx;   // per term: first entry in skipTbl, or 0xFFFFFFFF
+    const uint32_t* skipTbl;   // nRanges+1 offsets (relative to postOff[t]) per skipped term
+    const uint64_t* psOff; const int32_t* psDocs; uint32_t nSets;
+};
+
+struct infx_index {
+    infx_config cfg;
+    DevIndex d{};
+    std::vector<void*> allocs;
+    bool havePostings = false, haveDocs = false;
+    float avgdl = 0.f;
+    std::vector<uint64_t> hPostOff;   // host copy for capacity bounds / alg-bytes accounting
+    std::vector<int32_t> hDf;
+    std::vector<uint64_t> hPsOff;
+    int rank = 0, nranks = 1;
+};
+
+template <class Tp> static hipError_t dalloc(infx_index* ix, Tp** p, size_t n) {
+    void* v = nullptr; hipError_t e = hipMalloc(&v, std::max<size_t>(n, 1) * sizeof(Tp));
+    if (e == hipSuccess) { ix->allocs.push_back(v); *p = (Tp*)v; }
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// skip table build: one thread per (skipped term, range boundary)
+__global__ void k_build_skip(const uint64_t* postOff, const int32_t* postDoc, const uint32_t* skipTerms, uint32_t nSkip,
+                             uint32_t* skipTbl, int nRanges, int rshift) {
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t per = (uint64_t)nRanges + 1;
+    if (gid >= (uint64_t)nSkip * per) return;
+    uint32_t s = (uint32_t)(gid / per); int r = (int)(gid % per);
+    uint32_t t = skipTerms[s];
+    uint64_t lo = postOff[t], hi = postOff[t + 1];
+    int64_t target = (int64_t)r << rshift;
+    uint64_t a = lo, b = hi;
+    while (a < b) { uint64_t m = (a + b) >> 1; if ((int64_t)postDoc[m] < target) a = m + 1; else b = m; }
+    skipTbl[(uint64_t)s * per + r] = (uint32_t)(a - lo);
+}
+
+__global__ void k_doc_norm(const float* docLen, float* norm, int n, float bDivAvg) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float k1 = 1.2f, minDl = 1.f - 0.75f;
+    float t1 = bDivAvg * docLen[i];
+    float t2 = minDl + t1;
+    norm[i] = k1 * t2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct DevTerm {           // per (query term), device layout
+    uint64_t begin, end;   // absolute posting slice in postDoc/postW, or in extraDocs for virtual terms
+    float idf;
+    uint32_t skip;         // skipTbl base or 0xFFFFFFFF
+    uint8_t role, rank, isVirtual, pad;
+};
+struct DevQuery {
+    uint32_t termOff, numTerms;
+    int32_t mode, prefixSet, depth, nAnd;
+};
+struct SelRule {           // decided on the host from the (global) class counts
+    int32_t mode;          // INFX_MODE_*
+    int32_t cutoffRank;    // DISJ: include class&0x7F <= cutoff
+    uint32_t classMask;    // AND: include if (class & classMask) != 0
+    int32_t depth;
+};
+
+template <class Tp> __device__ __forceinline__ Tp rfl(Tp v) { return v; }
+__device__ __forceinline__ int rfl_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t rfl_u64(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t lo, uint64_t hi, int32_t target) {
+    while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (a[m] < target) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+// flags (uint16 per doc in LDS)
+//   AND : bits 0..7 count of ROLE_AND terms hit, bit 8 LOWEST hit, bit 9 S1, bit 10 S2
+//   DISJ: bits 0..7 (min rank + 1), 0 = not hit by a candidate-generating term
+//   PREFIX: bit 0 candidate
+#define F_LOWEST 0x100
+#define F_S1 0x200
+#define F_S2 0x400
+
+struct Arena {
+    int32_t* doc; float* score; uint8_t* cls;
+    unsigned long long* cursor; unsigned long long capacity;
+    uint2* blockOut;        // nq * nRanges : (offset low 32 | hi bits, count) — offset stored as 2x32 below
+    uint32_t* blockOutHi;
+    uint32_t* counts;       // nq * INFX_NCLASS
+    uint32_t* overflow;     // set to 1 when the arena would overflow
+    unsigned long long* algBytes;
+};
+
+template <int R>
+__global__ __launch_bounds__(WAVE) void k_accumulate(DevIndex ix, const DevQuery* __restrict__ queries,
+                                                      const DevTerm* __restrict__ terms, const int32_t* __restrict__ extraDocs,
+                                                      uint32_t nq, Arena ar) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sScore = (float*)smem;                          // R
+    uint16_t* sFlag = (uint16_t*)(smem + (size_t)R * 4);   // R
+    uint32_t* sLo = (uint32_t*)(smem + (size_t)R * 6);     // INFX_MAX_QUERY_TERMS+1 (slice begin, relative to term begin)
+    uint32_t* sHi = sLo + (INFX_MAX_QUERY_TERMS + 1);
+    uint32_t* sHist = sHi + (INFX_MAX_QUERY_TERMS + 1);    // INFX_NCLASS
+
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const uint32_t q = b % nq;
+    const int r = (int)(b / nq);
+    const DevQuery Q = queries[q];
+    const int mode = Q.mode;
+    const int nT = (int)Q.numTerms;
+    const DevTerm* T = terms + Q.termOff;
+    const int32_t base = r * R;                                    // shard-local doc id of the range start
+    const int32_t rend = min(base + R, ix.N);
+    uint32_t outCount = 0; unsigned long long outOff = 0;
+
+    // ---- slice bounds of every term in this range, one lane per term ------------------------------------------
+    // (prefix set = pseudo term nT)
+    bool anyGen = false;
+    for (int t0 = 0; t0 <= nT; t0 += WAVE) {
+        int t = t0 + lane;
+        uint32_t lo = 0, hi = 0; bool gen = false;
+        if (t < nT) {
+            DevTerm tm = T[t];
+            if (tm.skip != 0xFFFFFFFFu) { lo = ix.skipTbl[tm.skip + r]; hi = ix.skipTbl[tm.skip + r + 1]; }
+            else {
+                const int32_t* arr = tm.isVirtual ? extraDocs : ix.postDoc;
+                lo = (uint32_t)(lower_bound_i32(arr, tm.begin, tm.end, base) - tm.begin);
+                hi = (uint32_t)(lower_bound_i32(arr, tm.begin + lo, tm.end, rend) - tm.begin);
+            }
+            if (mode == INFX_MODE_AND) gen = (tm.role & (INFX_ROLE_S1 | INFX_ROLE_S2)) != 0;
+            else if (mode == INFX_MODE_DISJ) gen = (tm.role & (INFX_ROLE_ELIGIBLE | INFX_ROLE_LOWQ)) != 0;
+            sLo[t] = lo; sHi[t] = hi;
+        } else if (t == nT) {
+            if (Q.prefixSet >= 0) {
+                uint64_t pb = ix.psOff[Q.prefixSet], pe = ix.psOff[Q.prefixSet + 1];
+                lo = (uint32_t)(lower_bound_i32(ix.psDocs, pb, pe, base) - pb);
+                hi = (uint32_t)(lower_bound_i32(ix.psDocs, pb + lo, pe, rend) - pb);
+                gen = (mode == INFX_MODE_PREFIX);
+            }
+            sLo[t] = lo; sHi[t] = hi;
+        }
+        if (__ballot(gen && hi > lo)) anyGen = true;
+    }
+    if (!anyGen) {   // range-granular skip: nothing here can become a candidate
+        if (lane == 0) { ar.blockOut[(uint64_t)q * ix.nRanges + r] = make_uint2(0, 0); ar.blockOutHi[(uint64_t)q * ix.nRanges + r] = 0; }
+        return;
+    }
+    for (int i = lane; i < R; i += WAVE) { sScore[i] = 0.f; sFlag[i] = 0; }
+    for (int i = lane; i < INFX_NCLASS; i += WAVE) sHist[i] = 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS init visible to this wave's later accesses (single wave: program order)
+
+    // ---- PREFIX mode: mark the DocSet slice ---------------------------------------------------------------------
+    if (mode == INFX_MODE_PREFIX) {
+        uint64_t pb = ix.psOff[Q.prefixSet];
+        for (uint32_t i = sLo[nT] + lane; i < sHi[nT]; i += WAVE) sFlag[ix.psDocs[pb + i] - base] = 1;
+    }
+
+    // ---- stream every term once, in Bm25Scorer order (ascending termId) ----------------------------------------
+    unsigned long long myBytes = 0;
+    for (int t = 0; t < nT; t++) {
+        const uint32_t lo = sLo[t], hi = sHi[t];
+        if (hi <= lo) continue;
+        const DevTerm tm = T[t];
+        const float idf = tm.idf;
+        const uint8_t role = tm.role;
+        const uint16_t rk1 = (uint16_t)(tm.rank + 1);
+        const bool virt = tm.isVirtual != 0;
+        const int32_t* dptr = (virt ? extraDocs : ix.postDoc) + tm.begin;
+        const uint8_t* wptr = ix.postW + tm.begin;
+        if (lane == 0) myBytes += (unsigned long long)(hi - lo) * (virt ? 4u : 5u);
+        for (uint32_t i = lo + lane; i < hi; i += WAVE) {
+            int32_t doc = dptr[i];
+            float tf = virt ? 1.0f : (float)wptr[i];
+            int l = doc - base;
+            if (idf > 0.f) {     // Bm25Scorer.cs:301-309: terms with idf <= 0 are skipped by the scorer
+                float norm = ix.docNorm[doc];
+                float denom = tf + norm;
+                float core = (tf * (1.2f + 1.0f)) / denom;
+                float sc = idf * (core + 1.0f);
+                sScore[l] += sc;
+            }
+            if (mode == INFX_MODE_AND) {
+                uint16_t f = sFlag[l];
+                if (role & INFX_ROLE_AND) f = (uint16_t)((f & 0xFF00) | (((f & 0xFF) + 1) & 0xFF));
+                if (role & INFX_ROLE_LOWEST) f |= F_LOWEST;
+                if (role & INFX_ROLE_S1) f |= F_S1;
+                if (role & INFX_ROLE_S2) f |= F_S2;
+                sFlag[l] = f;
+            } else if (mode == INFX_MODE_DISJ) {
+                if (role & (INFX_ROLE_ELIGIBLE | INFX_ROLE_LOWQ)) {
+                    uint16_t f = sFlag[l];
+                    if (f == 0 || rk1 < f) sFlag[l] = rk1;
+                }
+            }
+        }
+    }
+
+    // ---- classify + count + compact ----------------------------------------------------------------------------------
+    const int nAnd = Q.nAnd;
+    // preseen set (non-PREFIX modes): docs whose upperBounds were pre-marked (TieredCandidateSelector.cs:74-77)
+    const uint64_t psb = (Q.prefixSet >= 0) ? ix.psOff[Q.prefixSet] : 0;
+    const uint32_t psLo = sLo[nT], psHi = sHi[nT];
+    // pass A: count emitted
+    uint32_t total = 0;
+    for (int i0 = 0; i0 < R; i0 += WAVE) {
+        int l = i0 + lane;
+        bool emit = false;
+        if (base + l < rend) {
+            uint16_t f = sFlag[l]; float sc = sScore[l];
+            if (sc > 0.f) {
+                if (mode == INFX_MODE_AND) emit = (f & (F_S1 | F_S2)) != 0;
+                else emit = f != 0;
+            }
+        }
+        total += __popcll(__ballot(emit));
+    }
+    if (total == 0) {
+        if (lane == 0) { ar.blockOut[(uint64_t)q * ix.nRanges + r] = make_uint2(0, 0); ar.blockOutHi[(uint64_t)q * ix.nRanges + r] = 0;
+                         atomicAdd(ar.algBytes, myBytes); }
+        return;
+    }
+    if (lane == 0) {
+        outOff = atomicAdd(ar.cursor, (unsigned long long)total);
+        if (outOff + total > ar.capacity) { atomicExch(ar.overflow, 1u); total = 0; }
+    }
+    outOff = rfl_u64(outOff); total = (uint32_t)rfl_i((int)total);
+    if (total == 0) { if (lane == 0) { ar.blockOut[(uint64_t)q * ix.nRanges + r] = make_uint2(0, 0); ar.blockOutHi[(uint64_t)q * ix.nRanges + r] = 0; } return; }
+    uint32_t w = 0;
+    for (int i0 = 0; i0 < R; i0 += WAVE) {
+        int l = i0 + lane;
+        bool emit = false; uint8_t cls = 0; float sc = 0.f;
+        if (base + l < rend) {
+            uint16_t f = sFlag[l]; sc = sScore[l];
+            if (sc > 0.f) {
+                if (mode == INFX_MODE_AND) {
+                    if (f & (F_S1 | F_S2)) {
+                        emit = true;
+                        int cnt = f & 0xFF;
+                        bool t1 = cnt == nAnd - 1;
+                        bool t0 = t1 && (f & F_LOWEST);
+                        cls = (uint8_t)((t0 ? 1 : 0) | ((t1 && nAnd >= 3) ? 2 : 0) | ((f & F_S1) ? 4 : 0) | ((f & F_S2) ? 8 : 0));
+                        atomicAdd(&sHist[cls], 1u);
+                    }
+                } else if (mode == INFX_MODE_DISJ) {
+                    if (f != 0) {
+                        emit = true;
+                        cls = (uint8_t)((f - 1) & 0x7F);
+                        bool pre = false;
+                        if (psHi > psLo) {
+                            int32_t d = base + l;
+                            uint64_t p = lower_bound_i32(ix.psDocs, psb + psLo, psb + psHi, d);
+                            pre = p < psb + psHi && ix.psDocs[p] == d;
+                        }
+                        if (pre) cls |= 0x80; else atomicAdd(&sHist[cls], 1u);
+                    }
+                } else {
+                    if (f != 0) { emit = true; cls = 1; atomicAdd(&sHist[1], 1u); }
+                }
+            }
+        }
+        unsigned long long m = __ballot(emit);
+        if (emit) {
+            uint32_t pos = w + __popcll(m & ((1ull << lane) - 1));
+            ar.doc[outOff + pos] = ix.docBase + base + l;
+            ar.score[outOff + pos] = sc;
+            ar.cls[outOff + pos] = cls;
+        }
+        w += __popcll(m);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int i = lane; i < INFX_NCLASS; i += WAVE) { uint32_t c = sHist[i]; if (c) atomicAdd(&ar.counts[(uint64_t)q * INFX_NCLASS + i], c); }
+    if (lane == 0) {
+        ar.blockOut[(uint64_t)q * ix.nRanges + r] = make_uint2((uint32_t)outOff, total);
+        ar.blockOutHi[(uint64_t)q * ix.nRanges + r] = (uint32_t)(outOff >> 32);
+        atomicAdd(ar.algBytes, myBytes + (unsigned long long)total * 12ull);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_select: one 256-thread block per query. Radix select on the 64-bit composite key
+//   (score bits << 32) | (0xFFFFFFFF - doc)   — descending — then LDS bitonic sort of the survivors.
+#define SEL_THREADS 256
+#define SEL_CAP 2048      // survivors sorted in LDS (>= max depth rounded up to a power of two)
+
+__device__ __forceinline__ bool sel_pass(const SelRule& rule, uint8_t c) {
+    if (rule.mode == INFX_MODE_AND) return (c & rule.classMask) != 0;
+    if (rule.mode == INFX_MODE_DISJ) return (int)(c & 0x7F) <= rule.cutoffRank;
+    return true;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void k_select(Arena ar, int nRanges, const SelRule* __restrict__ rules,
+                                                         infx_hit* __restrict__ out, uint32_t* __restrict__ outCount, int outStride) {
+    __shared__ uint32_t hist[4096];
+    __shared__ uint32_t part[SEL_THREADS];
+    __shared__ unsigned long long keys[SEL_CAP];
+    __shared__ uint32_t sCount, sBin, sRemain;
+    __shared__ unsigned long long sPrefix, sMask;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const SelRule rule = rules[q];
+    const int depth = rule.depth;
+    const uint2* bo = ar.blockOut + (uint64_t)q * nRanges;
+    const uint32_t* boh = ar.blockOutHi + (uint64_t)q * nRanges;
+
+    // total filtered count
+    if (tid == 0) sCount = 0;
+    __syncthreads();
+    {
+        uint32_t local = 0;
+        for (int r = 0; r < nRanges; r++) {
+            uint2 e = bo[r]; if (e.y == 0) continue;
+            uint64_t off = ((uint64_t)boh[r] << 32) | e.x;
+            for (uint32_t i = tid; i < e.y; i += SEL_THREADS) if (sel_pass(rule, ar.cls[off + i])) local++;
+        }
+        atomicAdd(&sCount, local);
+    }
+    __syncthreads();
+    uint32_t totalFiltered = sCount;
+    // threshold search: find prefix such that #keys > prefix-range fits
+    unsigned long long prefix = 0, mask = 0;   // keys matching (key & mask) == prefix are "undecided"
+    uint32_t remain = (uint32_t)depth;         // how many still to take from the undecided set
+    uint32_t undecided = totalFiltered;
+    // 12-bit digits from the top: {sign,exp,3 mantissa}, {12 mantissa}, {8 mantissa + 4 id}, ... ; last digit 4 bits
+    int shift = 52, width = 12;
+    while ((uint32_t)depth - remain + undecided > (uint32_t)SEL_CAP && shift >= 0) {
+        const uint32_t nb = 1u << width, dm = nb - 1u;
+        for (uint32_t i = tid; i < nb; i += SEL_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (int r = 0; r < nRanges; r++) {
+            uint2 e = bo[r]; if (e.y == 0) continue;
+            uint64_t off = ((uint64_t)boh[r] << 32) | e.x;
+            for (uint32_t i = tid; i < e.y; i += SEL_THREADS) {
+                if (!sel_pass(rule, ar.cls[off + i])) continue;
+                unsigned long long k = ((unsigned long long)__float_as_uint(ar.score[off + i]) << 32) | (0xFFFFFFFFu - (uint32_t)ar.doc[off + i]);
+                if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> shift) & dm], 1u);
+            }
+        }
+        __syncthreads();
+        // chunked suffix scan from the top bin: thread t owns bins [nb-16(t+1), nb-16t)
+        const uint32_t per = nb / SEL_THREADS ? nb / SEL_THREADS : 1;
+        uint32_t csum = 0;
+        if ((uint32_t)tid * per < nb) for (uint32_t j = 0; j < per; j++) csum += hist[nb - 1 - ((uint32_t)tid * per + j)];
+        part[tid] = csum;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t acc = 0; uint32_t c = 0;
+            uint32_t nchunks = nb / per;
+            for (; c < nchunks; c++) { if (acc + part[c] >= remain) break; acc += part[c]; }
+            if (c >= nchunks) c = nchunks - 1;
+            uint32_t bsel = 0;
+            for (uint32_t j = 0; j < per; j++) {
+                uint32_t bin = nb - 1 - (c * per + j);
+                if (acc + hist[bin] >= remain || j == per - 1) { bsel = bin; break; }
+                acc += hist[bin];
+            }
+            sBin = bsel; sRemain = remain - acc; sCount = hist[bsel];
+        }
+        __syncthreads();
+        // keys with a higher digit are all taken (gathered below via (k & mask) >= prefix); narrow the undecided set
+        prefix |= (unsigned long long)sBin << shift; mask |= (unsigned long long)dm << shift;
+        remain = sRemain; undecided = sCount;
+        if (shift == 4) { shift = 0; width = 4; } else if (shift == 0) shift = -1; else shift -= 12;
+        __syncthreads();
+    }
+    // gather: all keys strictly greater than the undecided range + the undecided keys themselves
+    // "greater": (k & mask) > prefix  (compare on the decided digits)
+    if (tid == 0) sCount = 0;
+    __syncthreads();
+    for (int r = 0; r < nRanges; r++) {
+        uint2 e = bo[r]; if (e.y == 0) continue;
+        uint64_t off = ((uint64_t)boh[r] << 32) | e.x;
+        for (uint32_t i = tid; i < e.y; i += SEL_THREADS) {
+            if (!sel_pass(rule, ar.cls[off + i])) continue;
+            unsigned long long k = ((unsigned long long)__float_as_uint(ar.score[off + i]) << 32) | (0xFFFFFFFFu - (uint32_t)ar.doc[off + i]);
+            if ((k & mask) >= prefix) { uint32_t p = atomicAdd(&sCount, 1u); if (p < SEL_CAP) keys[p] = k; }
+        }
+    }
+    __syncthreads();
+    uint32_t n = min(sCount, (uint32_t)SEL_CAP);
+    for (uint32_t i = n + tid; i < SEL_CAP; i += SEL_THREADS) keys[i] = 0ull;
+    __syncthreads();
+    // bitonic sort descending
+    for (uint32_t k = 2; k <= SEL_CAP; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < SEL_CAP; i += SEL_THREADS) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = keys[i], b2 = keys[ixj];
+                    bool up = (i & k) == 0;   // descending in "up" blocks
+                    if (up ? (a < b2) : (a > b2)) { keys[i] = b2; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    uint32_t take = min(n, (uint32_t)depth);
+    for (uint32_t i = tid; i < take; i += SEL_THREADS) {
+        unsigned long long k = keys[i];
+        infx_hit h; h.doc = (int32_t)(0xFFFFFFFFu - (uint32_t)k); h.score = __uint_as_float((uint32_t)(k >> 32));
+        out[(uint64_t)q * outStride + i] = h;
+    }
+    if (tid == 0) outCount[q] = take;
+}
+
+#include "stage2.hip.inc"
+
+// ---------------------------------------------------------------------------------------------------------------
+struct infx_stream {
+    infx_index* ix;
+    hipStream_t st = nullptr;
+    hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1;
+    // device workspaces (grown on demand)
+    void* dQueries = nullptr; size_t capQueries = 0;
+    void* dTerms = nullptr; size_t capTerms = 0;
+    void* dExtra = nullptr; size_t capExtra = 0;
+    void* dRules = nullptr; size_t capRules = 0;
+    void* dHits = nullptr; size_t capHits = 0;
+    void* dHitCount = nullptr; size_t capHitCount = 0;
+    void* dBlockOut = nullptr; size_t capBlockOut = 0;
+    void* dBlockOutHi = nullptr; size_t capBlockOutHi = 0;
+    void* dCounts = nullptr; size_t capCounts = 0;
+    void* dCovQ = nullptr; size_t capCovQ = 0;
+    void* dCovC = nullptr; size_t capCovC = 0;
+    void* dCovO = nullptr; size_t capCovO = 0;
+    int32_t* arDoc = nullptr; float* arScore = nullptr; uint8_t* arCls = nullptr; size_t arCap = 0;
+    unsigned long long* dCursor = nullptr;   // [0]=cursor [1]=algBytes
+    uint32_t* dOverflow = nullptr;
+    std::vector<infx_query> lastQ;            // kept between accumulate and select
+    uint32_t lastNq = 0;
+    float msAcc = 0, msSel = 0, msCov = 0;
+    uint64_t lastAlgBytes = 0;
+    bool timedAcc = false, timedSel = false, timedCov = false;
+};
+
+static int32_t grow(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return INFX_OK;
+    if (*p) hipFree(*p);
+    size_t n = std::max(need, *cap * 2);
+    if (hipMalloc(p, n) != hipSuccess) { *p = nullptr; *cap = 0; return fail(INFX_ENOMEM, "hipMalloc workspace failed%s"); }
+    *cap = n; return INFX_OK;
+}
+#define GROW(p, cap, need) do { int32_t rc_ = grow((void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)
+
+template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar) {
+    size_t lds = (size_t)R * 6 + (size_t)(INFX_MAX_QUERY_TERMS + 1) * 8 + INFX_NCLASS * 4;
+    uint64_t blocks = (uint64_t)nq * s->ix->d.nRanges;
+    k_accumulate<R><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
+                                                                           (const int32_t*)s->dExtra, nq, ar);
+}
+
+extern "C" {
+
+const char* infx_last_error(void) { return g_err.c_str(); }
+
+int32_t infx_create(const infx_config* cfg, infx_index** out) {
+    if (!cfg || !out) return fail(INFX_EINVAL, "null argument%s");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(INFX_EHIP, "no HIP device available (%s) — the GPU path is mandatory, there is no CPU fallback", hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(INFX_EINVAL, "bad device ordinal%s");
+    HIPCHK(hipSetDevice(cfg->device));
+    infx_index* ix = new infx_index();
+    ix->cfg = *cfg;
+    int R = cfg->range_docs ? cfg->range_docs : 2048;
+    if (R != 512 && R != 1024 && R != 2048 && R != 4096 && R != 8192) { delete ix; return fail(INFX_EINVAL, "range_docs must be a power of two in [512, 8192]%s"); }
+    ix->d.R = R; ix->d.rshift = __builtin_ctz(R);
+    if (ix->cfg.max_depth <= 0) ix->cfg.max_depth = 500;
+    if (ix->cfg.max_depth > SEL_CAP / 2) { delete ix; return fail(INFX_EINVAL, "max_depth too large%s"); }
+    *out = ix;
+    return INFX_OK;
+}
+
+void infx_destroy(infx_index* ix) {
+    if (!ix) return;
+    hipSetDevice(ix->cfg.device);
+    for (void* p : ix->allocs) hipFree(p);
+    delete ix;
+}
+
+int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float avgdl, const int64_t* doc_key,
+                         const uint64_t* text_offs, const uint16_t* text) {
+    if (!ix || !doc_len || !doc_key) return fail(INFX_EINVAL, "null argument%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    float *dLen = nullptr, *dNorm = nullptr; int64_t* dKey = nullptr; uint64_t* dTO = nullptr; uint16_t* dTx = nullptr;
+    HIPCHK(dalloc(ix, &dNorm, N)); HIPCHK(dalloc(ix, &dKey, N));
+    HIPCHK(hipMalloc((void**)&dLen, std::max<size_t>(N, 1) * 4));
+    HIPCHK(hipMemcpy(dLen, doc_len, (size_t)N * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dKey, doc_key, (size_t)N * 8, hipMemcpyHostToDevice));
+    float a = avgdl > 0.f ? avgdl : 1.f;
+    float bDivAvg = 0.75f / a;     // Vector256.Create(b / avgdl), Bm25Scorer.cs:390
+    if (N) k_doc_norm<<<(N + 255) / 256, 256>>>(dLen, dNorm, (int)N, bDivAvg);
+    HIPCHK(hipDeviceSynchronize());
+    hipFree(dLen);
+    if (text_offs && text) {
+        uint64_t tot = text_offs[N];
+        HIPCHK(dalloc(ix, &dTO, (size_t)N + 1)); HIPCHK(dalloc(ix, &dTx, (size_t)tot));
+        HIPCHK(hipMemcpy(dTO, text_offs, ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dTx, text, (size_t)tot * 2, hipMemcpyHostToDevice));
+    }
+    ix->d.N = (int32_t)N; ix->d.docNorm = dNorm; ix->d.docKey = dKey; ix->d.textOff = dTO; ix->d.text = dTx;
+    ix->d.nRanges = (int32_t)(((uint64_t)N + ix->d.R - 1) >> ix->d.rshift);
+    if (ix->d.nRanges == 0) ix->d.nRanges = 1;
+    if (ix->d.totalDocs == 0) ix->d.totalDocs = (int32_t)N;
+    ix->avgdl = avgdl; ix->haveDocs = true;
+    return INFX_OK;
+}
+
+int32_t infx_upload_postings(infx_index* ix, uint32_t T, const uint64_t* offs, const int32_t* doc_ids, const uint8_t* tf, const int32_t* df) {
+    if (!ix || !offs || !df) return fail(INFX_EINVAL, "null argument%s");
+    if (!ix->haveDocs) return fail(INFX_EINVAL, "infx_upload_docs must precede infx_upload_postings (range count)%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    uint64_t P = offs[T];
+    uint64_t* dOff = nullptr; int32_t* dDoc = nullptr; uint8_t* dW = nullptr;
+    HIPCHK(dalloc(ix, &dOff, (size_t)T + 1)); HIPCHK(dalloc(ix, &dDoc, (size_t)P)); HIPCHK(dalloc(ix, &dW, (size_t)P));
+    HIPCHK(hipMemcpy(dOff, offs, ((size_t)T + 1) * 8, hipMemcpyHostToDevice));
+    if (P) { HIPCHK(hipMemcpy(dDoc, doc_ids, (size_t)P * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dW, tf, (size_t)P, hipMemcpyHostToDevice)); }
+    ix->hPostOff.assign(offs, offs + T + 1); ix->hDf.assign(df, df + T);
+    // range skip tables for long lists: df >= 4 * nRanges (<= 1 B of table per posting)
+    int nR = ix->d.nRanges;
+    std::vector<uint32_t> skipIdx(T, 0xFFFFFFFFu), skipTerms;
+    uint64_t per = (uint64_t)nR + 1;
+    for (uint32_t t = 0; t < T; t++) {
+        uint64_t len = offs[t + 1] - offs[t];
+        if (len >= (uint64_t)4 * nR && len >= 256) { skipIdx[t] = (uint32_t)(skipTerms.size() * per); skipTerms.push_back(t); }
+    }
+    uint32_t *dSkipIdx = nullptr, *dSkipTbl = nullptr, *dSkipTerms = nullptr;
+    HIPCHK(dalloc(ix, &dSkipIdx, T)); HIPCHK(dalloc(ix, &dSkipTbl, skipTerms.size() * per));
+    HIPCHK(hipMemcpy(dSkipIdx, skipIdx.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    if (!skipTerms.empty()) {
+        if (skipTerms.size() * per > 0xFFFFFFF0ull) return fail(INFX_EINVAL, "skip table exceeds 32-bit indexing%s");
+        HIPCHK(hipMalloc((void**)&dSkipTerms, skipTerms.size() * 4));
+        HIPCHK(hipMemcpy(dSkipTerms, skipTerms.data(), skipTerms.size() * 4, hipMemcpyHostToDevice));
+        uint64_t tot = skipTerms.size() * per;
+        k_build_skip<<<(unsigned)((tot + 255) / 256), 256>>>(dOff, dDoc, dSkipTerms, (uint32_t)skipTerms.size(), dSkipTbl, nR, ix->d.rshift);
+        HIPCHK(hipDeviceSynchronize());
+        hipFree(dSkipTerms);
+    }
+    ix->d.T = (int32_t)T; ix->d.postOff = dOff; ix->d.postDoc = dDoc; ix->d.postW = dW; ix->d.skipIdx = dSkipIdx; ix->d.skipTbl = dSkipTbl;
+    ix->havePostings = true;
+    return INFX_OK;
+}
+
+int32_t infx_upload_prefix_docsets(infx_index* ix, uint32_t nsets, const uint64_t* offs, const int32_t* docs) {
+    if (!ix || (nsets && !offs)) return fail(INFX_EINVAL, "null argument%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    uint64_t* dOff = nullptr; int32_t* dDocs = nullptr;
+    uint64_t tot = nsets ? offs[nsets] : 0;
+    HIPCHK(dalloc(ix, &dOff, (size_t)nsets + 1)); HIPCHK(dalloc(ix, &dDocs, (size_t)tot));
+    if (nsets) { HIPCHK(hipMemcpy(dOff, offs, ((size_t)nsets + 1) * 8, hipMemcpyHostToDevice)); }
+    else { uint64_t z = 0; HIPCHK(hipMemcpy(dOff, &z, 8, hipMemcpyHostToDevice)); }
+    if (tot) HIPCHK(hipMemcpy(dDocs, docs, (size_t)tot * 4, hipMemcpyHostToDevice));
+    ix->d.psOff = dOff; ix->d.psDocs = dDocs; ix->d.nSets = nsets;
+    if (nsets) ix->hPsOff.assign(offs, offs + nsets + 1); else ix->hPsOff.assign(1, 0);
+    return INFX_OK;
+}
+
+int32_t infx_set_shard(infx_index* ix, int32_t rank, int32_t nranks, int32_t doc_base, int32_t total_docs) {
+    if (!ix || nranks < 1 || rank < 0 || rank >= nranks) return fail(INFX_EINVAL, "bad shard arguments%s");
+    ix->rank = rank; ix->nranks = nranks; ix->d.docBase = doc_base; ix->d.totalDocs = total_docs;
+    return INFX_OK;
+}
+
+int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
+    if (!ix || !out) return fail(INFX_EINVAL, "null argument%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    infx_stream* s = new infx_stream(); s->ix = ix;
+    HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+    hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1};
+    for (auto e : ev) HIPCHK(hipEventCreate(e));
+    HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
+    *out = s; return INFX_OK;
+}
+void infx_stream_destroy(infx_stream* s) {
+    if (!s) return;
+    hipSetDevice(s->ix->cfg.device);
+    void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dCounts,
+                  s->dCovQ, s->dCovC, s->dCovO, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow};
+    for (void* p : ps) if (p) hipFree(p);
+    hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1};
+    for (auto e : ev) hipEventDestroy(e);
+    if (s->st) hipStreamDestroy(s->st);
+    delete s;
+}
+
+int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
+                               uint32_t extra_n, const int32_t* extra_docs, infx_counts* counts_out) {
+    if (!s || !q || (nterms && !terms)) return fail(INFX_EINVAL, "null argument%s");
+    infx_index* ix = s->ix;
+    if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
+    if (nq == 0) return INFX_OK;
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    if ((uint64_t)nq * ix->d.nRanges > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nq * nRanges exceeds the grid limit; split the batch%s");
+    // translate + capacity bound
+    std::vector<DevQuery> dq(nq); std::vector<DevTerm> dt(nterms);
+    unsigned long long bound = 0;
+    for (uint32_t i = 0; i < nq; i++) {
+        const infx_query& Q = q[i];
+        if (Q.num_terms > INFX_MAX_QUERY_TERMS || (uint64_t)Q.term_off + Q.num_terms > nterms) return fail(INFX_EINVAL, "bad term range%s");
+        if (Q.depth <= 0 || Q.depth > ix->cfg.max_depth) return fail(INFX_EINVAL, "query depth exceeds infx_config.max_depth%s");
+        if (Q.mode < INFX_MODE_PREFIX || Q.mode > INFX_MODE_AND) return fail(INFX_EINVAL, "bad query mode%s");
+        if (Q.prefix_set >= (int32_t)ix->d.nSets || (Q.mode == INFX_MODE_PREFIX && Q.prefix_set < 0)) return fail(INFX_EINVAL, "bad prefix set%s");
+        dq[i] = DevQuery{Q.term_off, Q.num_terms, Q.mode, Q.prefix_set, Q.depth, Q.n_and};
+        unsigned long long qb = 0;
+        for (uint32_t k = 0; k < Q.num_terms; k++) {
+            const infx_term& tm = terms[Q.term_off + k];
+            DevTerm& D = dt[Q.term_off + k];
+            D.idf = tm.idf; D.role = tm.role; D.rank = tm.rank; D.pad = 0;
+            if (tm.term_id >= 0) {
+                if (tm.term_id >= ix->d.T) return fail(INFX_EINVAL, "term id out of range%s");
+                D.begin = ix->hPostOff[tm.term_id]; D.end = ix->hPostOff[tm.term_id + 1]; D.isVirtual = 0;
+                D.skip = 0;   // patched below from device table semantics: host mirrors the rule
+            } else {
+                if ((uint64_t)tm.extra_off + tm.extra_len > extra_n) return fail(INFX_EINVAL, "virtual term slice out of range%s");
+                D.begin = tm.extra_off; D.end = (uint64_t)tm.extra_off + tm.extra_len; D.isVirtual = 1; D.skip = 0xFFFFFFFFu;
+            }
+            bool gen = (Q.mode == INFX_MODE_AND && (tm.role & (INFX_ROLE_S1 | INFX_ROLE_S2))) ||
+                       (Q.mode == INFX_MODE_DISJ && (tm.role & (INFX_ROLE_ELIGIBLE | INFX_ROLE_LOWQ)));
+            if (gen) qb += D.end - D.begin;
+        }
+        if (Q.mode == INFX_MODE_PREFIX) qb = ix->hPsOff[Q.prefix_set + 1] - ix->hPsOff[Q.prefix_set];
+        bound += std::min<unsigned long long>(qb, (unsigned long long)ix->d.N);
+    }
+    // skip-table bases (same rule as infx_upload_postings)
+    {
+        // recompute lazily: a host mirror of skipIdx
+        static thread_local std::vector<uint32_t> dummy;
+    }
+    // arena
+    size_t need = (size_t)bound + 64;
+    if (need > s->arCap) {
+        if (need > ((size_t)1 << 31)) return fail(INFX_ECAPACITY, "candidate superset bound exceeds 2^31 entries; split the batch%s");
+        if (s->arDoc) { hipFree(s->arDoc); hipFree(s->arScore); hipFree(s->arCls); s->arDoc = nullptr; }
+        size_t n = std::max(need, s->arCap * 2);
+        if (hipMalloc((void**)&s->arDoc, n * 4) != hipSuccess || hipMalloc((void**)&s->arScore, n * 4) != hipSuccess || hipMalloc((void**)&s->arCls, n) != hipSuccess)
+            return fail(INFX_ENOMEM, "arena allocation failed%s");
+        s->arCap = n;
+    }
+    GROW(s->dQueries, s->capQueries, nq * sizeof(DevQuery));
+    GROW(s->dTerms, s->capTerms, std::max<size_t>(1, nterms) * sizeof(DevTerm));
+    GROW(s->dExtra, s->capExtra, std::max<size_t>(1, extra_n) * 4);
+    GROW(s->dBlockOut, s->capBlockOut, (size_t)nq * ix->d.nRanges * sizeof(uint2));
+    GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * ix->d.nRanges * 4);
+    GROW(s->dCounts, s->capCounts, (size_t)nq * INFX_NCLASS * 4);
+    // skip bases need the device skipIdx: fetch once per index into a host mirror
+    static std::mutex mu; static std::vector<std::pair<infx_index*, std::vector<uint32_t>>> mirrors;
+    const std::vector<uint32_t>* skipMirror = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& m : mirrors) if (m.first == ix && (int32_t)m.second.size() == ix->d.T) skipMirror = &m.second;
+        if (!skipMirror) {
+            std::vector<uint32_t> v((size_t)ix->d.T);
+            if (ix->d.T) HIPCHK(hipMemcpy(v.data(), ix->d.skipIdx, (size_t)ix->d.T * 4, hipMemcpyDeviceToHost));
+            mirrors.emplace_back(ix, std::move(v)); skipMirror = &mirrors.back().second;
+        }
+    }
+    for (uint32_t i = 0; i < nterms; i++) if (!dt[i].isVirtual) dt[i].skip = (*skipMirror)[terms[i].term_id];
+
+    HIPCHK(hipMemcpyAsync(s->dQueries, dq.data(), nq * sizeof(DevQuery), hipMemcpyHostToDevice, s->st));
+    if (nterms) HIPCHK(hipMemcpyAsync(s->dTerms, dt.data(), nterms * sizeof(DevTerm), hipMemcpyHostToDevice, s->st));
+    if (extra_n) HIPCHK(hipMemcpyAsync(s->dExtra, extra_docs, (size_t)extra_n * 4, hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemsetAsync(s->dCursor, 0, 16, s->st));
+    HIPCHK(hipMemsetAsync(s->dOverflow, 0, 4, s->st));
+    HIPCHK(hipMemsetAsync(s->dCounts, 0, (size_t)nq * INFX_NCLASS * 4, s->st));
+    Arena ar{s->arDoc, s->arScore, s->arCls, s->dCursor, (unsigned long long)s->arCap, (uint2*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
+             (uint32_t*)s->dCounts, s->dOverflow, s->dCursor + 1};
+    HIPCHK(hipEventRecord(s->evA0, s->st));
+    switch (ix->d.R) {
+        case 512: launch_acc<512>(s, nq, ar); break;
+        case 1024: launch_acc<1024>(s, nq, ar); break;
+        case 2048: launch_acc<2048>(s, nq, ar); break;
+        case 4096: launch_acc<4096>(s, nq, ar); break;
+        default: launch_acc<8192>(s, nq, ar); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->evA1, s->st));
+    s->timedAcc = true;
+    uint32_t ovf = 0; unsigned long long cur[2] = {0, 0};
+    if (counts_out) HIPCHK(hipMemcpyAsync(counts_out, s->dCounts, (size_t)nq * INFX_NCLASS * 4, hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipMemcpyAsync(&ovf, s->dOverflow, 4, hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipMemcpyAsync(cur, s->dCursor, 16, hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    if (ovf) return fail(INFX_ECAPACITY, "candidate arena overflow (bound violated)%s");
+    s->lastAlgBytes = cur[1];
+    s->lastQ.assign(q, q + nq); s->lastNq = nq;
+    return INFX_OK;
+}
+
+// TieredCandidateSelector tier rules evaluated from class counts (see header of this file / DESIGN.md)
+static SelRule make_rule(const infx_query& Q, const uint32_t* c) {
+    SelRule r{}; r.mode = Q.mode; r.depth = Q.depth; r.cutoffRank = 127; r.classMask = 0xFFFFFFFFu;
+    const long k = Q.depth;
+    if (Q.mode == INFX_MODE_AND) {
+        unsigned long long t0 = 0, t1 = 0;
+        for (int i = 0; i < 16; i++) { if (i & 1) t0 += c[i]; if (i & 2) t1 += c[i]; }
+        if ((long)t0 >= k * 2) { r.classMask = 1; return r; }                       // Tier 0 alone (:160-161)
+        unsigned long long g = t0; uint32_t gmask = 1;
+        if (Q.n_and >= 3 && (long)t0 < k * 3) { g = t1; gmask = 2 | 1; }            // Tier 1 (:165-171); T1 contains T0
+        if ((long)g < k * 5) {                                                      // Tier 2 (:174-234)
+            if (Q.df_s1 <= 0) { r.classMask = gmask; return r; }
+            if ((long)Q.df_s1 >= k * 10 || Q.df_s2 <= 0) { r.classMask = 4 | gmask; return r; }   // G u S1 == S1
+            r.classMask = 4 | 8 | gmask; return r;
+        }
+        r.classMask = gmask; return r;
+    }
+    if (Q.mode == INFX_MODE_DISJ) {
+        // SelectCandidatesDisjunctive (:260-319): ranks [0, n_and) are not low-quality, the rest are
+        int nElig = Q.n_and; bool hasSel = false; long local = 0; int cutoff = -1;
+        int nRanks = 0; for (int i = 127; i >= 0; i--) if (c[i]) { nRanks = i + 1; break; }
+        int totalRanks = std::max(nRanks, Q.df_s1);   // df_s1 carries the number of ranks in DISJ mode
+        for (int i = 0; i < totalRanks; i++) {
+            bool lowq = i >= nElig;
+            if (totalRanks > 1 && lowq && hasSel) continue;
+            cutoff = i; local += c[i];
+            if (!lowq && local > 0) hasSel = true;
+            if (local >= k * 100) break;
+        }
+        r.cutoffRank = cutoff; return r;
+    }
+    return r;
+}
+
+int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* counts, infx_hit* out, uint32_t* out_count) {
+    if (!s || !counts || !out || !out_count) return fail(INFX_EINVAL, "null argument%s");
+    if (nq == 0) return INFX_OK;
+    if (nq != s->lastNq) return fail(INFX_EINVAL, "infx_stage1_select must follow infx_stage1_accumulate of the same batch%s");
+    infx_index* ix = s->ix;
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    std::vector<SelRule> rules(nq);
+    int maxDepth = 0;
+    for (uint32_t i = 0; i < nq; i++) { rules[i] = make_rule(s->lastQ[i], counts[i].c); maxDepth = std::max(maxDepth, rules[i].depth); }
+    GROW(s->dRules, s->capRules, nq * sizeof(SelRule));
+    GROW(s->dHits, s->capHits, (size_t)nq * maxDepth * sizeof(infx_hit));
+    GROW(s->dHitCount, s->capHitCount, (size_t)nq * 4);
+    HIPCHK(hipMemcpyAsync(s->dRules, rules.data(), nq * sizeof(SelRule), hipMemcpyHostToDevice, s->st));
+    Arena ar{s->arDoc, s->arScore, s->arCls, s->dCursor, (unsigned long long)s->arCap, (uint2*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
+             (uint32_t*)s->dCounts, s->dOverflow, s->dCursor + 1};
+    HIPCHK(hipEventRecord(s->evS0, s->st));
+    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->evS1, s->st));
+    s->timedSel = true;
+    std::vector<infx_hit> tmp((size_t)nq * maxDepth);
+    HIPCHK(hipMemcpyAsync(tmp.data(), s->dHits, tmp.size() * sizeof(infx_hit), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipMemcpyAsync(out_count, s->dHitCount, (size_t)nq * 4, hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    // caller layout: nq * depth_i packed with the query's own depth as stride == we use max depth of the batch as stride
+    for (uint32_t i = 0; i < nq; i++) memcpy(out + (size_t)i * maxDepth, tmp.data() + (size_t)i * maxDepth, (size_t)out_count[i] * sizeof(infx_hit));
+    return INFX_OK;
+}
+
+int32_t infx_stage1_batch(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
+                          uint32_t extra_n, const int32_t* extra_docs, infx_hit* out, uint32_t* out_count) {
+    std::vector<infx_counts> counts(nq);
+    int32_t rc = infx_stage1_accumulate(s, nq, q, nterms, terms, extra_n, extra_docs, counts.data());
+    if (rc) return rc;
+    return infx_stage1_select(s, nq, counts.data(), out, out_count);
+}
+
+int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, uint32_t ncand, const infx_cov_cand* cand,
+                          infx_cov_out* out, int32_t want_features) {
+    if (!s || (ncand && (!q || !cand || !out))) return fail(INFX_EINVAL, "null argument%s");
+    if (ncand == 0) return INFX_OK;
+    infx_index* ix = s->ix;
+    if (!ix->haveDocs || !ix->d.text) return fail(INFX_EINVAL, "document text not uploaded%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    for (uint32_t i = 0; i < nq; i++)
+        if (q[i].num_tokens > INFX_MAX_QUERY_TOKENS || q[i].text_len > INFX_MAX_QUERY_CHARS || q[i].num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS)
+            return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope%s");
+    GROW(s->dCovQ, s->capCovQ, (size_t)nq * sizeof(infx_cov_query));
+    GROW(s->dCovC, s->capCovC, (size_t)ncand * sizeof(infx_cov_cand));
+    GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
+    HIPCHK(hipMemcpyAsync(s->dCovQ, q, (size_t)nq * sizeof(infx_cov_query), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipEventRecord(s->evC0, s->st));
+    k_stage2<<<(ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st>>>(ix->d, (const infx_cov_query*)s->dCovQ, nq,
+                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, want_features);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->evC1, s->st));
+    s->timedCov = true;
+    HIPCHK(hipMemcpyAsync(out, s->dCovO, (size_t)ncand * sizeof(infx_cov_out), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    return INFX_OK;
+}
+
+int32_t infx_last_timings(infx_stream* s, float* a, float* b, float* c) {
+    if (!s) return fail(INFX_EINVAL, "null argument%s");
+    if (s->timedAcc) hipEventElapsedTime(&s->msAcc, s->evA0, s->evA1);
+    if (s->timedSel) hipEventElapsedTime(&s->msSel, s->evS0, s->evS1);
+    if (s->timedCov) hipEventElapsedTime(&s->msCov, s->evC0, s->evC1);
+    if (a) *a = s->msAcc; if (b) *b = s->msSel; if (c) *c = s->msCov;
+    return INFX_OK;
+}
+int32_t infx_last_alg_bytes(infx_stream* s, uint64_t* bytes) {
+    if (!s || !bytes) return fail(INFX_EINVAL, "null argument%s");
+    *bytes = s->lastAlgBytes; return INFX_OK;
+}
+
+} // extern "C"
