@@ -1,0 +1,73 @@
+/*
+ * infidex_engine.h — C ABI of the host engine inside libinfidex_hip.so.
+ *
+ * The reference's host is C# (src/Infidex/SearchEngine.cs); this image has no .NET toolchain, so the host side above the
+ * device ABI (infidex_hip.h) is C++ and is exported here with the same surface for the hot path:
+ *   SearchEngine.CreateDefault()/CreateMinimal()  SearchEngine.cs:78-94   -> infx_engine_create
+ *   SearchEngine.IndexDocuments(IEnumerable<Document>)  :96-192           -> infx_engine_index_documents
+ *   SearchEngine.Search(Query)                          :256-319          -> infx_engine_search_batch (one Query per row;
+ *        Query.MaxNumberOfRecordsToReturn / CoverageDepth / EnableCoverage, Api/Query.cs:19,28,40)
+ *   SearchEngine.Dispose                                 :477             -> infx_engine_destroy
+ * A C# SearchEngine shim would call either this layer or infidex_hip.h directly.
+ * All functions return int32 status (INFX_OK = 0) unless documented otherwise; infx_engine_last_error() gives the text.
+ */
+#ifndef INFIDEX_ENGINE_H
+#define INFIDEX_ENGINE_H
+#include "infidex_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct infx_engine infx_engine;
+
+typedef struct infx_engine_config {
+    int32_t device;           /* HIP device ordinal; -1 = host-only engine (indexing / planning introspection; Search fails) */
+    int32_t range_docs;       /* see infx_config */
+    int32_t max_depth;        /* largest Query.CoverageDepth (default 500) */
+    int32_t threads;          /* host threads for indexing / query preparation; 0 = all cores */
+    int32_t enable_coverage;  /* CreateDefault: 1, CreateMinimal: 0 */
+    int32_t word_matcher;     /* CreateDefault: 1 (config 400 WordMatcherSetup), CreateMinimal: 0 */
+    int32_t stop_term_limit;  /* 0 = 1 250 000 */
+    int32_t want_features;    /* 1: Stage 2 also returns the integer feature vector (parity tests) */
+} infx_engine_config;
+
+const char* infx_engine_last_error(void);
+int32_t infx_engine_create(const infx_engine_config* cfg, infx_engine** out);
+void    infx_engine_destroy(infx_engine* e);
+
+/* n documents x field_count fields; field k of document d is arena[offs[d*field_count+k] .. offs[d*field_count+k+1]) (UTF-16);
+ * field_weights[k] in {0 High, 1 Med, 2 Low} (Api/Weight.cs); keys == NULL means DocumentKey = document index. */
+int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* keys, const uint16_t* arena, const uint64_t* offs,
+                                    int32_t field_count, const int32_t* field_weights);
+
+/* out_keys/out_scores/out_ties: nq x max_results (row-major); out_counts: nq; out_flags (may be NULL): bit0 query needs the
+ * short-query path (out of scope, empty result), bit1 coverage stage ran, bit2 coverage returned nothing -> Stage-1 fallback. */
+int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
+                                 int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
+                                 uint32_t* out_counts, uint32_t* out_flags);
+
+/* host_ms5: plan, stage1 (incl. transfers), stage-2 prep, stage2 (incl. transfers), final ordering;
+ * kernel_ms3: accumulate, select, stage2 kernel durations from HIP events on the launch stream;
+ * alg3: algorithmic bytes of the accumulate launch, Stage-2 candidate count, Stage-2 text bytes. */
+int32_t infx_engine_last_timings(infx_engine* e, double* host_ms5, float* kernel_ms3, uint64_t* alg3);
+
+/* ---- introspection used by the parity tests (host logic runs without a GPU) ---- */
+int32_t infx_engine_index_stats(infx_engine* e, int64_t* n_docs, int64_t* n_terms, int64_t* n_postings, float* avgdl);
+int32_t infx_engine_export_index(infx_engine* e, int32_t* df, uint64_t* post_off, int32_t* post_doc, uint8_t* post_w, float* doc_len);
+int32_t infx_engine_term_text(infx_engine* e, int32_t t, uint16_t* out, int32_t cap);
+int32_t infx_engine_match_ld1(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int32_t cap);
+int32_t infx_engine_plan(infx_engine* e, const uint16_t* q, int32_t len, int32_t depth, int32_t* term_ids, int32_t* dfs, float* idfs,
+                         uint8_t* roles, uint8_t* ranks, int32_t cap, int32_t* meta5, int32_t* flags);
+int64_t infx_engine_wordmatcher(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int64_t cap);
+int32_t infx_engine_prefix_pop(infx_engine* e, const uint16_t* p, int32_t len);
+int32_t infx_engine_last_stage1(infx_engine* e, uint32_t qi, int64_t* keys, float* scores, int32_t cap);
+int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* docs, float* base, float* scores, uint8_t* ties,
+                                int32_t* feat, int64_t cap);
+int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uint16_t* out, int32_t cap);
+int32_t infx_engine_device_handles(infx_engine* e, infx_index** idx, infx_stream** st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

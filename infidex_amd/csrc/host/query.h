@@ -1,0 +1,349 @@
+// Host-side query preparation of the product (what the reference does on the managed heap before / between the two
+// accelerated seams). Produces the flat records of include/infidex_hip.h.
+//   VectorModel.SearchWithMaxScore        Indexing/VectorModel.cs:376-602   -> plan_stage1
+//   FstIndex.MatchWithinEditDistance1     Indexing/Fst/FstIndex.cs:202-351  -> match_ld1 (same result set and order,
+//        computed with a pruned trie walk instead of visiting every node to depth m+1)
+//   TieredCandidateSelector (host-decidable part: prefix precedence, mode, tier roles)  Scoring/TieredCandidateSelector.cs:53-237
+//   WordMatcherLookup.Execute / WordMatcher.Lookup / LookupAffix   Scoring/WordMatcherLookup.cs, WordMatcher/WordMatcher.cs:201-354
+//   CoverageEngine.PrepareQuery           Coverage/CoverageEngine.cs:61-126,388-427
+//   List<T>.Sort semantics for the IDF ordering (BCL introsort; unstable above 16 elements) -> bcl_sort
+#pragma once
+#include "index.h"
+#include "../../../include/infidex_hip.h"
+#include <mutex>
+#include <unordered_map>
+#include <memory>
+#include <queue>
+
+namespace infx {
+
+// ---- BCL ArraySortHelper<T>.IntrospectiveSort (Comparison<T>) ------------------------------------------------------------
+// The reference orders terms with List<T>.Sort((a,b) => b.Idf.CompareTo(a.Idf)); equal-IDF terms end up in the order this
+// algorithm leaves them in, and that order decides which terms the 100*topK early stop / Tier 1 / Tier 2 pick.
+template <class T, class Cmp> struct BclSort {
+    T* k; Cmp cmp;
+    void sig(int i, int j) { if (cmp(k[i], k[j]) > 0) std::swap(k[i], k[j]); }
+    void ins(int lo, int n) { for (int i = 0; i < n - 1; i++) { T t = k[lo + i + 1]; int j = i; while (j >= 0 && cmp(t, k[lo + j]) < 0) { k[lo + j + 1] = k[lo + j]; j--; } k[lo + j + 1] = t; } }
+    void down(int lo, int i, int n) { T d = k[lo + i - 1]; while (i <= n / 2) { int c = 2 * i; if (c < n && cmp(k[lo + c - 1], k[lo + c]) < 0) c++; if (!(cmp(d, k[lo + c - 1]) < 0)) break; k[lo + i - 1] = k[lo + c - 1]; i = c; } k[lo + i - 1] = d; }
+    void heap(int lo, int n) { for (int i = n / 2; i >= 1; i--) down(lo, i, n); for (int i = n; i > 1; i--) { std::swap(k[lo], k[lo + i - 1]); down(lo, 1, i - 1); } }
+    int part(int lo, int n) {
+        int hi = n - 1, mid = hi >> 1; T* a = k + lo;
+        auto s2 = [&](int i, int j) { if (cmp(a[i], a[j]) > 0) std::swap(a[i], a[j]); };
+        s2(0, mid); s2(0, hi); s2(mid, hi);
+        T pivot = a[mid]; std::swap(a[mid], a[hi - 1]);
+        int l = 0, r = hi - 1;
+        while (l < r) { while (cmp(a[++l], pivot) < 0) {} while (cmp(pivot, a[--r]) < 0) {} if (l >= r) break; std::swap(a[l], a[r]); }
+        if (l != hi - 1) std::swap(a[l], a[hi - 1]);
+        return l;
+    }
+    void intro(int lo, int n, int depth) {
+        while (n > 1) {
+            if (n <= 16) { if (n == 2) { sig(lo, lo + 1); return; } if (n == 3) { sig(lo, lo + 1); sig(lo, lo + 2); sig(lo + 1, lo + 2); return; } ins(lo, n); return; }
+            if (depth == 0) { heap(lo, n); return; }
+            depth--;
+            int p = part(lo, n);
+            intro(lo + p + 1, n - (p + 1), depth);
+            n = p;
+        }
+    }
+};
+template <class T, class Cmp> inline void bcl_sort(std::vector<T>& v, Cmp cmp) {
+    int n = (int)v.size(); if (n < 2) return;
+    int lg = 0; for (unsigned x = (unsigned)n; x >>= 1;) lg++;
+    BclSort<T, Cmp> s{v.data(), cmp}; s.intro(0, n, 2 * (lg + 1));
+}
+
+// ---- LD1 term matching ----------------------------------------------------------------------------------------------------
+// Semantics of the reference walk: D[i][0] = i, D[0][j] = 0 (Myers' SEARCH variant: the query may match a suffix of the
+// path), a final node at depth j <= m+1 is reported when D[m][j] <= 1; nodes are visited in label order (pre-order).
+// A subtree is skipped when min_i(D[i][j] + max(0, j-1-i)) > 1: completing the pattern from row i needs m-i more text
+// characters but at most m+1-j remain below depth m+1, and a fresh start (row 0) deeper than column 2 costs >= 2.
+inline int match_ld1(const HostIndex& ix, uview q, std::vector<int>& out, int cap = 1024) {
+    out.clear();
+    int m = (int)q.size();
+    if (m == 0 || m > 64 || ix.trie.empty()) return 0;
+    int count = 0;
+    std::vector<std::vector<int>> col(m + 3, std::vector<int>(m + 1));
+    for (int i = 0; i <= m; i++) col[0][i] = i;
+    struct Fr { uint32_t node; int depth; };
+    std::vector<Fr> st;
+    // push children of root in reverse so that popping yields ascending labels
+    auto push_children = [&](uint32_t node, int depth) {
+        size_t base = st.size();
+        for (uint32_t c = ix.trie[node].firstChild; c; c = ix.trie[c].nextSibling) st.push_back({c, depth});
+        std::reverse(st.begin() + base, st.end());
+    };
+    push_children(0, 1);
+    while (!st.empty()) {
+        Fr f = st.back(); st.pop_back();
+        const auto& nd = ix.trie[f.node];
+        int j = f.depth;
+        const std::vector<int>& p = col[j - 1]; std::vector<int>& c = col[j];
+        c[0] = 0;
+        for (int i = 1; i <= m; i++) {
+            int v = p[i - 1] + (q[i - 1] == nd.label ? 0 : 1);
+            v = std::min(v, p[i] + 1); v = std::min(v, c[i - 1] + 1);
+            c[i] = v;
+        }
+        if (nd.term >= 0 && c[m] <= 1) { if (count < cap) out.push_back(nd.term); count++; }
+        if (j >= m + 1) continue;
+        int best = 1 << 20;
+        for (int i = 0; i <= m; i++) best = std::min(best, c[i] + std::max(0, j - 1 - i));
+        if (best > 1) continue;
+        push_children(f.node, j + 1);
+    }
+    return count;
+}
+
+// ---- Stage-1 plan -----------------------------------------------------------------------------------------------------------
+struct FuzzyUnion { std::vector<int32_t> docs; };
+struct FuzzyCache {
+    std::mutex mu; std::unordered_map<std::u16string, std::shared_ptr<FuzzyUnion>> map;
+    std::shared_ptr<FuzzyUnion> get(const ustr& k) { std::lock_guard<std::mutex> l(mu); auto it = map.find(k); return it == map.end() ? nullptr : it->second; }
+    void put(const ustr& k, std::shared_ptr<FuzzyUnion> v) { std::lock_guard<std::mutex> l(mu); if (map.size() > 100000) map.clear(); map[k] = v; }
+};
+
+struct QueryPlan {
+    bool blank = false, unsupported = false;
+    ustr qtext;          // lower(normalize(trim(raw)))  == Query.Text inside SearchEngine.Search
+    ustr searchText;     // normalised again by SearchPipeline.Execute
+    ustr tfidfQuery;
+    std::vector<infx_term> terms;                    // Bm25Scorer order
+    std::vector<std::shared_ptr<FuzzyUnion>> fuzzy;  // per term (null for index terms)
+    infx_query q{};
+    bool noTerms = false;
+};
+
+inline void analyze_query(uview text, int minIndexSize, bool& canUse, bool& mixed, ustr& longWords) {   // QueryAnalyzer.cs:10-54
+    canUse = false; mixed = false; longWords.assign(text);
+    int shortCnt = 0, longCnt = 0; ustr joined; bool any = false;
+    for_each_word(text, [&](int off, int len) { any = true; if (len >= minIndexSize) { if (longCnt++) joined.push_back(u' '); joined.append(text.substr(off, len)); } else shortCnt++; });
+    if (!any) { canUse = (int)text.size() >= minIndexSize; return; }
+    if (longCnt > 0) { canUse = true; longWords = joined; }
+    if (shortCnt > 0 && longCnt > 0) mixed = true;
+}
+
+inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int depth, QueryPlan& P) {
+    P = QueryPlan();
+    size_t b = 0, e = raw.size();
+    while (b < e && is_ws(raw[b])) b++;
+    while (e > b && is_ws(raw[e - 1])) e--;
+    normalize_into(raw.substr(b, e - b), P.qtext); lower_inplace(P.qtext);
+    bool allws = true; for (u16 c : P.qtext) if (!is_ws(c)) { allws = false; break; }
+    if (allws) { P.blank = true; return; }
+    normalize_into(P.qtext, P.searchText);
+    const int n = ix.cfg.ngram;
+    bool canUse, mixed; ustr longWords;
+    analyze_query(P.searchText, n, canUse, mixed, longWords);
+    if (!canUse) { P.unsupported = true; return; }
+    P.tfidfQuery = mixed ? longWords : P.searchText;
+    { bool ws = true; for (u16 c : P.tfidfQuery) if (!is_ws(c)) { ws = false; break; } if (ws) P.tfidfQuery = P.searchText; }
+
+    // raw tokens: words first, then n-grams of the padded text; at most 128 (VectorModel.cs:381,407)
+    struct Raw { int id; ustr text; };
+    std::vector<Raw> rawTok;
+    ustr text = normalize(P.tfidfQuery);
+    auto visit = [&](uview s) { if (rawTok.size() >= 128) return; int64_t id = ix.terms.keys.find(s); if (id >= 0) rawTok.push_back({(int)id, ustr()}); else rawTok.push_back({-1, ustr(s)}); };
+    for_each_word(text, [&](int off, int len) { if (len >= n) visit(uview(text.data() + off, len)); });
+    ustr padded((size_t)ix.cfg.startPad, (u16)0xFFFF); padded += text; padded.append((size_t)ix.cfg.stopPad, (u16)0xFFFE);
+    if ((int)padded.size() >= n)
+        for (int i = 0; i + n <= (int)padded.size(); i++) {
+            bool allpad = true; for (int k = 0; k < n; k++) if (padded[i + k] != 0xFFFF && padded[i + k] != 0xFFFE) { allpad = false; break; }
+            if (!allpad) visit(uview(padded.data() + i, n));
+        }
+    std::sort(rawTok.begin(), rawTok.end(), [](const Raw& a, const Raw& c) { return a.id != c.id ? a.id < c.id : a.text < c.text; });
+    rawTok.erase(std::unique(rawTok.begin(), rawTok.end(), [](const Raw& a, const Raw& c) { return a.id == c.id && a.text == c.text; }), rawTok.end());
+
+    const int N = ix.N;
+    const float avgdl = ix.avgdl > 0.f ? ix.avgdl : 1.f;
+    struct TI { int termId; int df; float idf, maxScore; std::shared_ptr<FuzzyUnion> fz; };
+    std::vector<TI> tis;
+    for (auto& r : rawTok) {
+        int df = 0; std::shared_ptr<FuzzyUnion> fz;
+        if (r.id >= 0) df = ix.df[r.id];
+        else if (r.text.size() >= 4) {      // ExpandMissingTerm (VectorModel.cs:643-743)
+            fz = fc.get(r.text);
+            if (!fz) {
+                std::vector<int> m; match_ld1(ix, r.text, m, 1024);
+                std::vector<int32_t> all;
+                for (int id : m) if (ix.df[id] > 0) all.insert(all.end(), ix.terms.doc.begin() + ix.terms.off[id], ix.terms.doc.begin() + ix.terms.off[id + 1]);
+                fz = std::make_shared<FuzzyUnion>();
+                if (!all.empty()) { std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end()); fz->docs.swap(all); }
+                fc.put(r.text, fz);
+            }
+            df = (int)fz->docs.size();
+            if (df == 0) fz = nullptr;
+        }
+        if (df <= 0 || df > ix.cfg.stopTermLimit) continue;
+        float idf = compute_idf(N, df);
+        const float maxTf = 255.f, k1 = 1.2f, bb = 0.75f, delta = 1.0f;
+        float minDlNorm = 1.f - bb + bb * (1.f / avgdl);
+        float maxCore = (maxTf * (k1 + 1.f)) / (maxTf + k1 * minDlNorm);
+        tis.push_back({r.id, df, idf, idf * (maxCore + delta), fz});
+    }
+    if (tis.empty()) { P.noTerms = true; return; }
+    const int nT = (int)tis.size();
+    P.terms.resize(nT); P.fuzzy.resize(nT);
+    for (int i = 0; i < nT; i++) {
+        infx_term& t = P.terms[i]; std::memset(&t, 0, sizeof t);
+        t.term_id = tis[i].termId; t.idf = tis[i].idf; t.max_score = tis[i].maxScore; P.fuzzy[i] = tis[i].fz;
+        if (tis[i].fz) t.extra_len = (uint32_t)tis[i].fz->docs.size();
+    }
+    infx_query& Q = P.q; std::memset(&Q, 0, sizeof Q);
+    Q.num_terms = (uint32_t)nT; Q.depth = depth; Q.prefix_set = -1;
+    const long k = depth;
+    // prefix precedence (TieredCandidateSelector.cs:66-82, 455-532); originalQuery == the text handed to SearchWithMaxScore
+    {
+        ustr ql = P.tfidfQuery; lower_inplace(ql);
+        int maxLen = std::min((int)ql.size(), 3);
+        for (int len = maxLen; len >= 1; len--) {
+            int64_t pk = ix.prefixKeys.find(uview(ql.data(), len));
+            if (pk < 0) continue;
+            long pop = ix.prefixPop[pk];
+            if (pop == 0) continue;
+            if (pop > k * 20) continue;
+            if (pop <= k * 10) {
+                Q.prefix_set = ix.prefixSetId[pk];
+                if (pop >= std::min(k * 2, 100L)) { Q.mode = INFX_MODE_PREFIX; return; }
+                break;   // pre-seen docs only
+            }
+        }
+    }
+    bool typo = false; float maxIdf = 0.f;
+    for (auto& t : tis) { if (t.df < 10) typo = true; if (t.idf > maxIdf) maxIdf = t.idf; }
+    struct Ord { int idx; float idf; };
+    std::vector<Ord> ord(nT);
+    for (int i = 0; i < nT; i++) ord[i] = {i, tis[i].idf};
+    bcl_sort(ord, [](const Ord& a, const Ord& c) { return c.idf < a.idf ? -1 : (c.idf > a.idf ? 1 : 0); });
+    if (typo || nT == 1) {
+        Q.mode = INFX_MODE_DISJ;
+        int nElig = 0;
+        for (int r = 0; r < nT; r++) {
+            infx_term& t = P.terms[ord[r].idx];
+            bool lowq = ord[r].idf < (maxIdf * 0.2f);
+            t.role = lowq ? INFX_ROLE_LOWQ : INFX_ROLE_ELIGIBLE; t.rank = (uint8_t)r;
+            if (!lowq) nElig = r + 1;
+        }
+        Q.n_and = nElig; Q.df_s1 = nT;
+        return;
+    }
+    Q.mode = INFX_MODE_AND; Q.n_and = nT;
+    for (int r = 0; r < nT; r++) P.terms[ord[r].idx].role = (r < nT - 1) ? INFX_ROLE_AND : INFX_ROLE_LOWEST;
+    {
+        int sel = 0, cap = std::min(2, nT); float cutoff = maxIdf * 0.3f;
+        for (int r = 0; r < nT && sel < cap; r++) {
+            if (ord[r].idf <= 0.f || ord[r].idf < cutoff) continue;
+            P.terms[ord[r].idx].role |= (sel == 0 ? INFX_ROLE_S1 : INFX_ROLE_S2);
+            if (sel == 0) Q.df_s1 = tis[ord[r].idx].df; else Q.df_s2 = tis[ord[r].idx].df;
+            sel++;
+        }
+    }
+}
+
+// ---- WordMatcher lookups ---------------------------------------------------------------------------------------------------
+struct DocList { const int32_t* p; size_t n; };
+struct WmResult { std::vector<DocList> lists; std::vector<std::vector<int32_t>> owned; bool any = false; };
+
+inline void wm_collect(const HostIndex& ix, uview queryText, bool coverPrefixSuffix, WmResult& R) {
+    R = WmResult();
+    if (!ix.cfg.wordMatcher) return;
+    auto add = [&](const Csr& c, uview key) { int64_t id = c.keys.find(key); if (id >= 0 && c.len((uint32_t)id) > 0) R.lists.push_back({c.doc.data() + c.off[id], (size_t)c.len((uint32_t)id)}); };
+    std::vector<std::pair<int, int>> words;
+    for_each_word(queryText, [&](int off, int len) { if (len >= 2) words.push_back({off, len}); });
+    R.owned.reserve(words.size() * 2);
+    for (auto& w : words) {
+        uview word = queryText.substr(w.first, w.second);
+        ustr nw(word); lower_inplace(nw); nw = normalize(nw);
+        int L = (int)nw.size();
+        add(ix.wmExact, nw);
+        if (L >= ix.cfg.wmMinLD1 && L <= ix.cfg.wmMaxLD1) {
+            add(ix.wmLd1, nw);
+            ustr d;
+            for (int i = 0; i < L; i++) { d.assign(nw); d.erase(i, 1); add(ix.wmLd1, d); add(ix.wmExact, d); }
+        }
+        if (coverPrefixSuffix && !nw.empty()) {    // LookupAffix: <= 4096 trie terms, prefix hits first, then suffix hits
+            auto lo = std::lower_bound(ix.affixFwd.begin(), ix.affixFwd.end(), nw, [&](uint32_t a, const ustr& kx) { return ix.words.key(a) < uview(kx); });
+            auto hi = lo; while (hi != ix.affixFwd.end() && ix.words.key(*hi).substr(0, nw.size()) == uview(nw)) ++hi;
+            ustr rn(nw.rbegin(), nw.rend());
+            auto revKeyLess = [&](uint32_t a, const ustr& kx) {   // compare reversed(word a) < kx
+                uview x = ix.words.key(a); size_t nx = x.size(), nk = kx.size(), nmin = std::min(nx, nk);
+                for (size_t i = 0; i < nmin; i++) { u16 cx = x[nx - 1 - i]; if (cx != kx[i]) return cx < kx[i]; }
+                return nx < nk;
+            };
+            auto rlo = std::lower_bound(ix.affixRev.begin(), ix.affixRev.end(), rn, revKeyLess);
+            auto ends_with = [&](uint32_t a) { uview x = ix.words.key(a); return x.size() >= nw.size() && x.substr(x.size() - nw.size()) == uview(nw); };
+            auto rhi = rlo; while (rhi != ix.affixRev.end() && ends_with(*rhi)) ++rhi;
+            size_t pc = hi - lo, sc = rhi - rlo;
+            if (pc || sc) {
+                std::vector<int32_t> docs; size_t budget = 4096;
+                size_t take = std::min(pc, budget);
+                for (size_t i = 0; i < take; i++) docs.push_back(ix.wordLastDoc[*(lo + i)]);
+                budget -= take; take = std::min(sc, budget);
+                for (size_t i = 0; i < take; i++) docs.push_back(ix.wordLastDoc[*(rlo + i)]);
+                std::sort(docs.begin(), docs.end()); docs.erase(std::unique(docs.begin(), docs.end()), docs.end());
+                R.owned.push_back(std::move(docs));
+            }
+        }
+    }
+    for (auto& o : R.owned) if (!o.empty()) R.lists.push_back({o.data(), o.size()});
+    R.any = !R.lists.empty();
+}
+inline bool wm_contains(const WmResult& R, int32_t doc) {
+    for (auto& l : R.lists) if (std::binary_search(l.p, l.p + l.n, doc)) return true;
+    return false;
+}
+// first `limit` ids of the union in ascending order that are not in `exclude` (sorted)
+inline void wm_first_unique(const WmResult& R, const std::vector<int32_t>& excludeSorted, size_t limit, std::vector<int32_t>& out) {
+    out.clear();
+    if (limit == 0 || R.lists.empty()) return;
+    using E = std::pair<int32_t, size_t>;   // (doc, list)
+    std::priority_queue<E, std::vector<E>, std::greater<E>> pq;
+    std::vector<size_t> pos(R.lists.size(), 0);
+    for (size_t i = 0; i < R.lists.size(); i++) if (R.lists[i].n) pq.push({R.lists[i].p[0], i});
+    int32_t last = -1;
+    while (!pq.empty() && out.size() < limit) {
+        E e2 = pq.top(); pq.pop();
+        size_t li = e2.second;
+        if (++pos[li] < R.lists[li].n) pq.push({R.lists[li].p[pos[li]], li});
+        if (e2.first == last) continue;
+        last = e2.first;
+        if (std::binary_search(excludeSorted.begin(), excludeSorted.end(), e2.first)) continue;
+        out.push_back(e2.first);
+    }
+}
+
+// ---- CoverageEngine.PrepareQuery -------------------------------------------------------------------------------------------
+inline int32_t prepare_cov_query(const HostIndex& ix, uview query, infx_cov_query& C) {
+    std::memset(&C, 0, sizeof C);
+    if ((int)query.size() > INFX_MAX_QUERY_CHARS) return INFX_EUNSUPPORTED;
+    std::memcpy(C.text, query.data(), query.size() * 2); C.text_len = (int)query.size();
+    struct Tk { int off, len; };
+    std::vector<Tk> raw, uq, fus;
+    for_each_word(query, [&](int off, int len) { fus.push_back({off, len}); if (len >= 2) raw.push_back({off, len}); });
+    for (auto& t : raw) {
+        bool dup = false;
+        for (auto& u : uq) if (u.len == t.len && query.substr(u.off, u.len) == query.substr(t.off, t.len)) { dup = true; break; }
+        if (!dup) uq.push_back(t);
+    }
+    if ((int)uq.size() > INFX_MAX_QUERY_TOKENS || (int)fus.size() > 2 * INFX_MAX_QUERY_TOKENS) return INFX_EUNSUPPORTED;
+    C.num_tokens = (int)uq.size();
+    const int n = ix.cfg.ngram;
+    for (int i = 0; i < (int)uq.size(); i++) {
+        if (uq[i].len > 62) return INFX_EUNSUPPORTED;
+        C.tok_off[i] = (uint16_t)uq[i].off; C.tok_len[i] = (uint16_t)uq[i].len;
+        uview term = query.substr(uq[i].off, uq[i].len);
+        float sum = 0.f; int cnt = 0;
+        if (ix.N > 0 && (int)term.size() >= n)
+            for (int j = 0; j + n <= (int)term.size(); j++) { int64_t id = ix.terms.keys.find(term.substr(j, n)); if (id >= 0 && ix.df[id] > 0) { sum += compute_idf(ix.N, ix.df[id]); cnt++; } }
+        C.term_idf[i] = cnt > 0 ? sum / (float)cnt : log2f((float)(term.size() + 1));
+        int64_t w = ix.words.find(term);   // WordIdfCache is OrdinalIgnoreCase; both sides are lower-case here
+        C.word_idf[i] = (w >= 0 && ix.wordDf[w] > 0 && (int)ix.wordDf[w] <= ix.N) ? ix.wordIdf[w] : 0.f;
+    }
+    C.has_word_idf = uq.empty() ? 0 : 1;
+    C.num_fusion_tokens = (int)fus.size();
+    for (int i = 0; i < (int)fus.size(); i++) { C.ftok_off[i] = (uint16_t)fus[i].off; C.ftok_len[i] = (uint16_t)std::min(fus[i].len, 65535); }
+    C.lcs_tolerance = (int)query.size() >= 5 ? (int)((double)query.size() * 0.2) : 0;
+    return INFX_OK;
+}
+
+} // namespace infx

@@ -1,0 +1,84 @@
+// Host-side text layer of the product (C++ stands in for the reference's C# host; no .NET toolchain in the image).
+// Mirrors, for the hot path only:
+//   Tokenization/TextNormalizer.cs:120-200, 203-304   Normalize + default diacritic map
+//   Tokenization/TokenizerSetup.cs:36-43              delimiters
+//   string.ToLowerInvariant (simple 1:1 case mapping; table-driven, ASCII + Latin-1 + Latin Ext-A + Greek/Cyrillic)
+// Table-driven: one 64 Ki-entry fold table per operation, built once.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <string_view>
+
+namespace infx {
+
+using u16 = char16_t;
+using ustr = std::u16string;
+using uview = std::u16string_view;
+
+struct TextTables {
+    std::vector<u16> lower;      // ToLowerInvariant
+    std::vector<u16> norm;       // TextNormalizer char map (+ \t \n \r -> ' ')
+    std::vector<uint8_t> delim;  // tokenizer delimiters
+    TextTables() : lower(65536), norm(65536), delim(65536, 0) {
+        for (int i = 0; i < 65536; i++) { lower[i] = (u16)i; norm[i] = (u16)i; }
+        for (int c = 'A'; c <= 'Z'; c++) lower[c] = (u16)(c + 32);
+        for (int c = 0xC0; c <= 0xDE; c++) if (c != 0xD7) lower[c] = (u16)(c + 32);
+        auto pairEvenUp = [&](int a, int b) { for (int c = a; c <= b; c += 2) lower[c] = (u16)(c + 1); };
+        pairEvenUp(0x100, 0x12E); pairEvenUp(0x132, 0x136); pairEvenUp(0x139, 0x147); pairEvenUp(0x14A, 0x176); pairEvenUp(0x179, 0x17D);
+        lower[0x178] = 0xFF;
+        for (int c = 0x391; c <= 0x3A9; c++) if (c != 0x3A2) lower[c] = (u16)(c + 32);
+        for (int c = 0x410; c <= 0x42F; c++) lower[c] = (u16)(c + 32);
+        for (int c = 0x400; c <= 0x40F; c++) lower[c] = (u16)(c + 80);
+        static const char16_t* from = u"ÆæØøÅåÄäÖöÜüßŠšČčŘřŽžŇňŤťĎďĚěÁáÉéÍíÓóÚúÝýŮůĄąĆćĘęŁłŃńŚśŹźŻżŐőŰűĂăÂâÎîȘșȚțĞğİıŞşÀàÇçÈèÊêËëÌìÏïÑñÒòÔôÕõÙùÛûŸÿÐðÞþ";
+        static const char16_t* to   = u"EeOoAaAaOoUusSsCcRrZzNnTtDdEeAaEeIiOoUuYyUuAaCcEeLlNnSsZzZzOoUuAaAaIiSsTtGgIiSsAaCcEeEeEeIiIiNnOoOoOoUuUuYyDdTt";
+        for (int i = 0; from[i]; i++) norm[from[i]] = to[i];
+        norm[u'\t'] = norm[u'\n'] = norm[u'\r'] = u' ';
+        const u16 d[] = {u' ',u'-',u'/',u'.',u',',u':',u';',u'\'',u'`',0x2013,0x2014,u'*',u'&',u'\\',u'_',u'(',u')',u'{',u'}',u'[',u']',u'\t'};
+        for (u16 c : d) delim[c] = 1;
+    }
+};
+inline const TextTables& tables() { static TextTables t; return t; }
+
+// TextNormalizer.NormalizeWithStandardWhitespace: map chars, collapse runs of spaces.
+inline void normalize_into(uview in, ustr& out) {
+    const auto& T = tables();
+    out.clear(); out.reserve(in.size());
+    bool prev = false;
+    for (u16 c : in) {
+        u16 m = T.norm[c];
+        bool sp = m == u' ';
+        if (sp && prev) continue;
+        out.push_back(m); prev = sp;
+    }
+}
+inline ustr normalize(uview in) { ustr o; normalize_into(in, o); return o; }
+inline void lower_inplace(ustr& s) { const auto& T = tables(); for (auto& c : s) c = T.lower[c]; }
+inline bool is_ws(u16 c) {
+    return c == 0x20 || (c >= 0x09 && c <= 0x0D) || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) ||
+           c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+}
+inline bool is_delim(u16 c) { return tables().delim[c] != 0; }
+
+struct Span { int off, len; };
+// maximal runs of non-delimiters (Tokenizer.cs:108-138, string.Split(delims, RemoveEmptyEntries))
+template <class F> inline void for_each_word(uview s, F&& f) {
+    const auto& T = tables();
+    int n = (int)s.size(), i = 0;
+    while (i < n) {
+        while (i < n && T.delim[s[i]]) i++;
+        if (i >= n) break;
+        int st = i;
+        while (i < n && !T.delim[s[i]]) i++;
+        f(st, i - st);
+    }
+}
+
+inline uint64_t hash_u16(const u16* p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; h ^= h >> 29; }
+    h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32;
+    return h;
+}
+
+} // namespace infx

@@ -1,0 +1,266 @@
+"""ctypes binding of libinfidex_hip.so with the reference's public names for the hot path.
+
+Mirrors (reference paths under src/Infidex): SearchEngine.cs (CreateDefault/CreateMinimal/IndexDocuments/Search),
+Api/Query.cs, Api/Result.cs, Core/Document.cs, Api/Weight.cs, Core/ScoreEntry.cs.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass, field as _dc_field
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libinfidex_hip.so")
+
+INFX_NFEAT = 32
+STATUS = {0: "INFX_OK", 1: "INFX_EINVAL", 2: "INFX_ENOMEM", 3: "INFX_EHIP", 4: "INFX_ECAPACITY", 5: "INFX_EUNSUPPORTED"}
+
+
+class InfidexError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Weight:      # Api/Weight.cs:7-26
+    High, Med, Low = 0, 1, 2
+
+
+@dataclass
+class Field:       # Api/Field.cs (name, value, weight)
+    name: str
+    value: str
+    weight: int = Weight.Med
+
+
+@dataclass
+class Document:    # Core/Document.cs:76-88 (single text => one 'content' field, Weight.Med)
+    document_key: int
+    fields: Union[str, Sequence[Field]]
+
+    def field_list(self) -> List[Field]:
+        return [Field("content", self.fields, Weight.Med)] if isinstance(self.fields, str) else list(self.fields)
+
+
+@dataclass
+class Query:       # Api/Query.cs:9-40
+    text: str
+    max_number_of_records_to_return: int = 10
+    coverage_depth: int = 500
+    enable_coverage: bool = True
+
+
+@dataclass
+class ScoreEntry:  # Core/ScoreEntry.cs
+    score: float
+    document_id: int
+    tiebreaker: int = 0
+
+
+@dataclass
+class Result:      # Api/Result.cs
+    records: List[ScoreEntry] = _dc_field(default_factory=list)
+    unsupported: bool = False
+    used_coverage: bool = False
+    stage1_fallback: bool = False
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("device", C.c_int32), ("range_docs", C.c_int32), ("max_depth", C.c_int32), ("threads", C.c_int32),
+                ("enable_coverage", C.c_int32), ("word_matcher", C.c_int32), ("stop_term_limit", C.c_int32),
+                ("want_features", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the in-tree HIP extension; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise InfidexError(3, f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.infx_engine_last_error.restype = C.c_char_p
+        L.infx_last_error.restype = C.c_char_p
+        L.infx_engine_wordmatcher.restype = C.c_int64
+        L.infx_engine_last_stage2.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _u16(s: str) -> np.ndarray:
+    return np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16).copy()
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty)) if a is not None else None
+
+
+def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
+    arrs = [_u16(t) for t in texts]
+    offs = np.zeros(len(arrs) + 1, np.uint64)
+    if arrs:
+        offs[1:] = np.cumsum([len(a) for a in arrs])
+    arena = np.concatenate(arrs) if arrs and offs[-1] > 0 else np.zeros(1, np.uint16)
+    return arena, offs
+
+
+class SearchEngine:
+    def __init__(self, enable_coverage=True, word_matcher=True, device: int = 0, range_docs: int = 0, max_depth: int = 500,
+                 threads: int = 0, stop_term_limit: int = 0, want_features: bool = False):
+        self.L = load_library()
+        cfg = _Cfg(device, range_docs, max_depth, threads, int(enable_coverage), int(word_matcher), stop_term_limit, int(want_features))
+        h = C.c_void_p()
+        self._check(self.L.infx_engine_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    # SearchEngine.cs:78-94
+    @classmethod
+    def create_default(cls, **kw):
+        return cls(enable_coverage=True, word_matcher=True, **kw)
+
+    @classmethod
+    def create_minimal(cls, **kw):
+        return cls(enable_coverage=False, word_matcher=False, **kw)
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.L.infx_engine_last_error()
+            raise InfidexError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.infx_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- indexing ----
+    def index_documents(self, docs: Sequence[Document]):
+        docs = list(docs)
+        if not docs:
+            return self.index_flat(None, np.zeros(1, np.uint16), np.zeros(1, np.uint64), (Weight.Med,))
+        fl0 = docs[0].field_list()
+        weights = [f.weight for f in fl0]
+        texts = []
+        for d in docs:
+            fl = d.field_list()
+            if [f.weight for f in fl] != weights:
+                raise InfidexError(1, "all documents of one IndexDocuments call must share the field schema")
+            texts.extend(str(f.value) for f in fl)
+        arena, offs = pack_texts(texts)
+        keys = np.asarray([d.document_key for d in docs], np.int64)
+        return self.index_flat(keys, arena, offs, weights)
+
+    def index_flat(self, keys, arena, offs, field_weights=(Weight.Med,)):
+        fw = np.asarray(field_weights, np.int32)
+        n = (len(offs) - 1) // len(fw)
+        keys = None if keys is None else np.ascontiguousarray(keys, np.int64)
+        self._keep = (keys, arena, offs)
+        self._check(self.L.infx_engine_index_documents(self.h, C.c_int64(n), _p(keys, C.c_int64), _p(arena, C.c_uint16),
+                                                       _p(offs, C.c_uint64), len(fw), _p(fw, C.c_int32)))
+        self._keep = None
+
+    # ---- search ----
+    def search(self, query: Union[Query, str], max_results: Optional[int] = None) -> Result:
+        q = query if isinstance(query, Query) else Query(query, max_results or 10)
+        return self.search_batch([q.text], q.max_number_of_records_to_return, q.coverage_depth, q.enable_coverage)[0]
+
+    def search_batch_raw(self, texts: Sequence[str], max_results=10, depth=500, enable_coverage=True):
+        arena, offs = pack_texts(texts)
+        return self.search_packed(arena, offs, max_results, depth, enable_coverage)
+
+    def search_packed(self, arena, offs, max_results=10, depth=500, enable_coverage=True):
+        nq = len(offs) - 1
+        keys = np.full((nq, max_results), -1, np.int64); scores = np.zeros((nq, max_results), np.float32)
+        ties = np.zeros((nq, max_results), np.uint8); counts = np.zeros(nq, np.uint32); flags = np.zeros(nq, np.uint32)
+        self._check(self.L.infx_engine_search_batch(self.h, nq, _p(arena, C.c_uint16), _p(offs, C.c_uint64), max_results, depth,
+                                                    int(enable_coverage), _p(keys, C.c_int64), _p(scores, C.c_float),
+                                                    _p(ties, C.c_uint8), _p(counts, C.c_uint32), _p(flags, C.c_uint32)))
+        return keys, scores, ties, counts, flags
+
+    def search_batch(self, texts: Sequence[str], max_results=10, depth=500, enable_coverage=True) -> List[Result]:
+        keys, scores, ties, counts, flags = self.search_batch_raw(texts, max_results, depth, enable_coverage)
+        out = []
+        for i in range(len(texts)):
+            recs = [ScoreEntry(float(scores[i, k]), int(keys[i, k]), int(ties[i, k])) for k in range(int(counts[i]))]
+            out.append(Result(recs, bool(flags[i] & 1), bool(flags[i] & 2), bool(flags[i] & 4)))
+        return out
+
+    def last_timings(self):
+        host = np.zeros(5, np.float64); kern = np.zeros(3, np.float32); alg = np.zeros(3, np.uint64)
+        self._check(self.L.infx_engine_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))
+        return {"plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
+                "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
+                "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2])}
+
+    # ---- introspection (parity tests) ----
+    def index_stats(self):
+        n = C.c_int64(); t = C.c_int64(); p = C.c_int64(); a = C.c_float()
+        self._check(self.L.infx_engine_index_stats(self.h, C.byref(n), C.byref(t), C.byref(p), C.byref(a)))
+        return {"docs": n.value, "terms": t.value, "postings": p.value, "avgdl": a.value}
+
+    def export_index(self):
+        s = self.index_stats()
+        T, P, N = s["terms"], s["postings"], s["docs"]
+        df = np.zeros(T, np.int32); off = np.zeros(T + 1, np.uint64); pd = np.zeros(max(P, 1), np.int32)
+        pw = np.zeros(max(P, 1), np.uint8); dl = np.zeros(max(N, 1), np.float32)
+        self._check(self.L.infx_engine_export_index(self.h, _p(df, C.c_int32), _p(off, C.c_uint64), _p(pd, C.c_int32), _p(pw, C.c_uint8), _p(dl, C.c_float)))
+        return {"df": df, "post_off": off, "post_doc": pd[:P], "post_w": pw[:P], "doc_len": dl[:N], "avgdl": s["avgdl"]}
+
+    def term_text(self, t):
+        buf = np.zeros(256, np.uint16)
+        n = self.L.infx_engine_term_text(self.h, int(t), _p(buf, C.c_uint16), 256)
+        return buf[:max(n, 0)].tobytes().decode("utf-16-le", errors="surrogatepass")
+
+    def match_ld1(self, q, cap=1024):
+        a = _u16(q); out = np.zeros(cap, np.int32)
+        c = self.L.infx_engine_match_ld1(self.h, _p(a, C.c_uint16), len(a), _p(out, C.c_int32), cap)
+        return c, out[:min(c, cap)].copy()
+
+    def plan(self, text, depth=500, cap=256):
+        a = _u16(text)
+        t = np.zeros(cap, np.int32); df = np.zeros(cap, np.int32); idf = np.zeros(cap, np.float32)
+        roles = np.zeros(cap, np.uint8); ranks = np.zeros(cap, np.uint8); meta = np.zeros(5, np.int32); flags = C.c_int32(0)
+        n = self.L.infx_engine_plan(self.h, _p(a, C.c_uint16), len(a), depth, _p(t, C.c_int32), _p(df, C.c_int32), _p(idf, C.c_float),
+                                    _p(roles, C.c_uint8), _p(ranks, C.c_uint8), cap, _p(meta, C.c_int32), C.byref(flags))
+        return {"term_ids": t[:n].copy(), "df": df[:n].copy(), "idf": idf[:n].copy(), "roles": roles[:n].copy(), "ranks": ranks[:n].copy(),
+                "mode": int(meta[0]), "prefix_set": int(meta[1]), "n_and": int(meta[2]), "df_s1": int(meta[3]), "df_s2": int(meta[4]),
+                "flags": flags.value}
+
+    def wordmatcher(self, text, cap=1 << 22):
+        a = _u16(text); out = np.zeros(cap, np.int32)
+        n = self.L.infx_engine_wordmatcher(self.h, _p(a, C.c_uint16), len(a), _p(out, C.c_int32), C.c_int64(cap))
+        return out[:min(n, cap)].copy()
+
+    def prefix_pop(self, p):
+        a = _u16(p)
+        return int(self.L.infx_engine_prefix_pop(self.h, _p(a, C.c_uint16), len(a)))
+
+    def last_stage1(self, qi, cap=4096):
+        keys = np.zeros(cap, np.int64); sc = np.zeros(cap, np.float32)
+        n = self.L.infx_engine_last_stage1(self.h, qi, _p(keys, C.c_int64), _p(sc, C.c_float), cap)
+        n = max(n, 0)
+        return keys[:n].copy(), sc[:n].copy()
+
+    def last_stage2(self, cap=1 << 20):
+        qo = np.zeros(cap, np.uint32); docs = np.zeros(cap, np.int32); base = np.zeros(cap, np.float32); sc = np.zeros(cap, np.float32)
+        ties = np.zeros(cap, np.uint8); feat = np.zeros((cap, INFX_NFEAT), np.int32)
+        n = self.L.infx_engine_last_stage2(self.h, _p(qo, C.c_uint32), _p(docs, C.c_int32), _p(base, C.c_float), _p(sc, C.c_float),
+                                           _p(ties, C.c_uint8), _p(feat, C.c_int32), C.c_int64(cap))
+        n = min(int(n), cap)
+        return qo[:n].copy(), docs[:n].copy(), base[:n].copy(), sc[:n].copy(), ties[:n].copy(), feat[:n].copy()
+
+
+def normalize(s, lower=False):
+    L = load_library()
+    x = _u16(s); out = np.zeros(len(x) + 8, np.uint16)
+    n = L.infx_engine_normalize(_p(x, C.c_uint16), len(x), int(lower), _p(out, C.c_uint16), len(out))
+    return out[:n].tobytes().decode("utf-16-le")
