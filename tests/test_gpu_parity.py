@@ -101,8 +101,15 @@ def compare_batch(e, o, queries, k, depth=500, check_features=True):
             tids, tbase, tsc, tties, tfeat = o.last_trace()
             if check_features and set(od) == set(gd):
                 assert len(idxs) == len(tids), (q, len(idxs), len(tids))
-                for a, i in enumerate(idxs):
-                    assert docs[i] == tids[a], (q, a)
+                # same evaluations; the order inside the TF-IDF section may differ between documents whose Stage-1 scores
+                # differ by less than SCORE_RTOL (quirk Q9), so pair records by (document, occurrence number)
+                assert sorted(docs[idxs].tolist()) == sorted(tids.tolist()), q
+                occ_o = {}; slot = {}
+                for a, d in enumerate(tids.tolist()):
+                    slot[(d, occ_o.setdefault(d, 0))] = a; occ_o[d] += 1
+                occ_g = {}
+                for i in idxs:
+                    d = int(docs[i]); a = slot[(d, occ_g.setdefault(d, 0))]; occ_g[d] += 1
                     if not np.array_equal(feat[i, :O.N_INT_FEAT], tfeat[a, :O.N_INT_FEAT]):
                         stats["feat_mismatch"] += 1
                         bad = [O.FEAT_NAMES[j] for j in range(O.N_INT_FEAT) if feat[i, j] != tfeat[a, j]]
