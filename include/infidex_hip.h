@@ -43,7 +43,7 @@ typedef struct infx_stream infx_stream;   /* per-caller HIP stream + workspace *
 /* Replaces the constants of Bm25Scorer.cs:21-23 / ConfigurationParameters.cs:101-104. */
 typedef struct infx_config {
     int32_t device;          /* HIP device ordinal */
-    int32_t range_docs;      /* documents per LDS range block (power of two, 512..8192); 0 = default 2048 */
+    int32_t range_docs;      /* documents per LDS range block (power of two, 512..8192); 0 = default 1024 */
     int32_t max_depth;       /* largest Query.CoverageDepth that will be used (default 500) */
     int32_t reserved;
 } infx_config;
@@ -158,11 +158,12 @@ typedef struct infx_cov_out {
     uint8_t lcs;           /* min(lcs,255) when want_lcs */
     uint8_t status;        /* 0 ok, INFX_EUNSUPPORTED when the text exceeds INFX_MAX_DOC_TOKENS */
     int32_t word_hits_full;
-    int32_t feat[INFX_NFEAT];   /* CoverageFeatures / FusionSignals ints (bit-exact parity target), layout in DESIGN.md */
 } infx_cov_out;
 
+/* feat_out (may be NULL): ncand x INFX_NFEAT ints — CoverageFeatures / FusionSignals (the bit-exact parity target; the
+ * reference keeps them internal, Coverage/CoverageFeatures.cs:3-88), layout in DESIGN.md. */
 int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, uint32_t ncand,
-                          const infx_cov_cand* cand, infx_cov_out* out, int32_t want_features);
+                          const infx_cov_cand* cand, infx_cov_out* out, int32_t* feat_out);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------ */
 /* Durations (ms) of the last Stage-1 accumulate / select / Stage-2 launches on this stream, from HIP events recorded on

@@ -10,6 +10,8 @@
 #include "../../../include/infidex_engine.h"
 #include <chrono>
 #include <unordered_map>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace infx;
 
@@ -41,7 +43,7 @@ struct infx_engine {
     // last-batch introspection for parity tests
     std::vector<QueryPlan> lastPlans;
     std::vector<infx_hit> lastHits; std::vector<uint32_t> lastHitCount; int lastStride = 0;
-    std::vector<infx_cov_cand> lastCands; std::vector<infx_cov_out> lastOuts;
+    std::vector<infx_cov_cand> lastCands; std::vector<infx_cov_out> lastOuts; std::vector<int32_t> lastFeat;
 };
 
 extern "C" {
@@ -115,9 +117,10 @@ int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_
     double t0 = now_ms();
     // ---------------- Stage-1 planning (host, parallel over queries) ----------------
     std::vector<QueryPlan>& plans = e->lastPlans; plans.assign(nq, QueryPlan());
-    parallel_for(nq, threads, [&](int64_t b, int64_t en, int) {
+    parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; i++) plan_stage1(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i]);
     });
+    double tPlanPar = now_ms() - t0;
     std::vector<infx_query> dq; std::vector<infx_term> dterms; std::vector<int32_t> extra; std::vector<uint32_t> qmap;   // device batch -> query index
     for (uint32_t i = 0; i < nq; i++) {
         QueryPlan& P = plans[i];
@@ -158,7 +161,7 @@ int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_
     std::vector<infx_cov_query> covQ(nq);
     std::vector<int32_t> covErr(nq, 0);
     const bool covEnabled = ix.cfg.enableCoverage && enable_coverage;
-    parallel_for(nq, threads, [&](int64_t b, int64_t en, int) {
+    parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         WmResult wm; std::vector<int32_t> sortedTop, overlap, uniq;
         for (int64_t i = b; i < en; i++) {
             QueryPlan& P = plans[i]; PerQ& S = pq[i];
@@ -222,15 +225,16 @@ int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_
     std::vector<infx_cov_out>& outs = e->lastOuts; outs.assign(cands.size(), infx_cov_out{});
     e->s2Candidates = cands.size(); e->s2TextBytes = 0;
     for (auto& c : cands) e->s2TextBytes += 2 * (ix.textOff[c.doc + 1] - ix.textOff[c.doc]);
+    if (e->cfg.want_features) e->lastFeat.assign(cands.size() * INFX_NFEAT, 0);
     if (!cands.empty()) {
-        int32_t rc = infx_stage2_batch(e->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)cands.size(), cands.data(), outs.data(), e->cfg.want_features);
+        int32_t rc = infx_stage2_batch(e->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)cands.size(), cands.data(), outs.data(), e->cfg.want_features ? e->lastFeat.data() : nullptr);
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(e->stream, nullptr, nullptr, &e->msCov);
         for (auto& o : outs) if (o.status) return efail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)");
     }
     double t4 = now_ms();
     // ---------------- final ordering / truncation (host) ----------------
-    parallel_for(nq, threads, [&](int64_t b, int64_t en, int) {
+    parallel_dyn(nq, threads, 8, [&](int64_t b, int64_t en, int) {
         std::vector<Entry> fin, cons;
         for (int64_t i = b; i < en; i++) {
             PerQ& S = pq[i]; const QueryPlan& P = plans[i];
@@ -278,6 +282,15 @@ int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_
         }
     });
     double t5 = now_ms();
+    if (getenv("INFX_DEBUG")) {
+        int nm[4] = {0, 0, 0, 0}; unsigned long long dfsum[4] = {0, 0, 0, 0}; size_t maxT = 0;
+        for (auto& P : plans) { if (P.blank || P.unsupported || P.noTerms) continue; nm[P.q.mode]++; maxT = std::max(maxT, P.terms.size());
+            for (auto& t : P.terms) dfsum[P.q.mode] += t.term_id >= 0 ? (unsigned long long)ix.terms.len((uint32_t)t.term_id) : t.extra_len; }
+        fprintf(stderr, "[infx] modes: prefix=%d disj=%d and=%d | postings per mode: %llu %llu %llu | maxT=%zu\n", nm[1], nm[2], nm[3], dfsum[1], dfsum[2], dfsum[3], maxT);
+        fprintf(stderr, "[infx] nq=%u dev=%u terms=%zu extra=%zu cands=%zu | plan %.1f (build %.1f) s1 %.1f prep2 %.1f s2 %.1f post %.1f ms | fuzzy calls=%lld %.1f ms-cpu (ld1 %.1f) docs=%lld\n",
+                nq, nd, dterms.size(), extra.size(), cands.size(), t1 - t0, tPlanPar, t2 - t1, t3 - t2, t4 - t3, t5 - t4,
+                (long long)e->fuzzy.fuzzyCalls.exchange(0), e->fuzzy.fuzzyNs.exchange(0) / 1e6, e->fuzzy.ld1Ns.exchange(0) / 1e6, (long long)e->fuzzy.fuzzyDocs.exchange(0));
+    }
     e->tPrep1 = t1 - t0; e->tStage1 = t2 - t1; e->tPrep2 = t3 - t2; e->tStage2 = t4 - t3; e->tPost = t5 - t4;
     return INFX_OK;
 }
@@ -366,7 +379,7 @@ int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* doc
         const infx_cov_cand& c = e->lastCands[i]; const infx_cov_out& o = e->lastOuts[i];
         if (query_of) query_of[i] = c.query; if (docs) docs[i] = c.doc; if (base) base[i] = c.base_score;
         if (scores) scores[i] = o.score; if (ties) ties[i] = o.tiebreaker;
-        if (feat) std::memcpy(feat + (size_t)i * INFX_NFEAT, o.feat, INFX_NFEAT * 4);
+        if (feat) { if (e->lastFeat.size() >= (size_t)(i + 1) * INFX_NFEAT) std::memcpy(feat + (size_t)i * INFX_NFEAT, e->lastFeat.data() + (size_t)i * INFX_NFEAT, INFX_NFEAT * 4); else std::memset(feat + (size_t)i * INFX_NFEAT, 0, INFX_NFEAT * 4); }
     }
     return n;
 }

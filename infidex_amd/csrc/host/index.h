@@ -35,6 +35,17 @@ template <class F> inline void parallel_for(int64_t n, int threads, F&& f) {   /
     for (auto& x : th) x.join();
 }
 
+// dynamic scheduling: items are handed out in small grains so that a few expensive items (fuzzy expansions, dense
+// WordMatcher words) do not serialise behind one thread
+template <class F> inline void parallel_dyn(int64_t n, int threads, int64_t grain, F&& f) {   // f(begin, end, threadIndex)
+    if (threads <= 1 || n <= grain) { f((int64_t)0, n, 0); return; }
+    std::atomic<int64_t> next(0);
+    int nt = (int)std::min<int64_t>(threads, (n + grain - 1) / grain);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([&, t] { for (;;) { int64_t b = next.fetch_add(grain); if (b >= n) break; f(b, std::min(n, b + grain), t); } });
+    for (auto& x : th) x.join();
+}
+
 // ---- string -> dense id table (open addressing, keys in an arena) -----------------------------------------------
 struct KeyTable {
     std::vector<u16> arena;

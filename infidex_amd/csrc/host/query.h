@@ -14,6 +14,7 @@
 #include <unordered_map>
 #include <memory>
 #include <queue>
+#include <chrono>
 
 namespace infx {
 
@@ -98,6 +99,7 @@ inline int match_ld1(const HostIndex& ix, uview q, std::vector<int>& out, int ca
 // ---- Stage-1 plan -----------------------------------------------------------------------------------------------------------
 struct FuzzyUnion { std::vector<int32_t> docs; };
 struct FuzzyCache {
+    std::atomic<long long> fuzzyNs{0}, fuzzyCalls{0}, fuzzyDocs{0}, ld1Ns{0};   // instrumentation (INFX_DEBUG)
     std::mutex mu; std::unordered_map<std::u16string, std::shared_ptr<FuzzyUnion>> map;
     std::shared_ptr<FuzzyUnion> get(const ustr& k) { std::lock_guard<std::mutex> l(mu); auto it = map.find(k); return it == map.end() ? nullptr : it->second; }
     void put(const ustr& k, std::shared_ptr<FuzzyUnion> v) { std::lock_guard<std::mutex> l(mu); if (map.size() > 100000) map.clear(); map[k] = v; }
@@ -164,12 +166,25 @@ inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
         else if (r.text.size() >= 4) {      // ExpandMissingTerm (VectorModel.cs:643-743)
             fz = fc.get(r.text);
             if (!fz) {
+                auto tF0 = std::chrono::steady_clock::now();
                 std::vector<int> m; match_ld1(ix, r.text, m, 1024);
-                std::vector<int32_t> all;
-                for (int id : m) if (ix.df[id] > 0) all.insert(all.end(), ix.terms.doc.begin() + ix.terms.off[id], ix.terms.doc.begin() + ix.terms.off[id + 1]);
+                fc.ld1Ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tF0).count();
+                // union of the matched terms' (sorted) posting lists: pairwise merges, smallest lists first
+                std::vector<std::pair<const int32_t*, size_t>> lists;
+                for (int id : m) if (ix.df[id] > 0 && ix.terms.len((uint32_t)id)) lists.push_back({ix.terms.doc.data() + ix.terms.off[id], (size_t)ix.terms.len((uint32_t)id)});
+                std::sort(lists.begin(), lists.end(), [](auto& a, auto& c) { return a.second < c.second; });
                 fz = std::make_shared<FuzzyUnion>();
-                if (!all.empty()) { std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end()); fz->docs.swap(all); }
+                std::vector<int32_t> acc, tmp;
+                for (auto& l : lists) {
+                    if (acc.empty()) { acc.assign(l.first, l.first + l.second); continue; }
+                    tmp.resize(acc.size() + l.second);
+                    tmp.resize(std::set_union(acc.begin(), acc.end(), l.first, l.first + l.second, tmp.begin()) - tmp.begin());
+                    acc.swap(tmp);
+                }
+                fz->docs.swap(acc);
                 fc.put(r.text, fz);
+                fc.fuzzyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tF0).count();
+                fc.fuzzyCalls++; fc.fuzzyDocs += (long long)fz->docs.size();
             }
             df = (int)fz->docs.size();
             if (df == 0) fz = nullptr;
@@ -225,6 +240,14 @@ inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
             if (!lowq) nElig = r + 1;
         }
         Q.n_and = nElig; Q.df_s1 = nT;
+        // Once a processed term alone holds >= 100*topK (+ the < 100 pre-seen) documents, localCount >= 100*topK after it and the
+        // loop breaks (:317-318): no later rank can generate candidates. They keep scoring, but stop marking (smaller supersets).
+        for (int r = 0; r < nT; r++) {
+            if ((long)tis[ord[r].idx].df >= k * 100 + 100) {
+                for (int r2 = r + 1; r2 < nT; r2++) P.terms[ord[r2].idx].role = 0;
+                break;
+            }
+        }
         return;
     }
     Q.mode = INFX_MODE_AND; Q.n_and = nT;

@@ -103,6 +103,8 @@ struct SelRule {           // decided on the host from the (global) class counts
     int32_t cutoffRank;    // DISJ: include class&0x7F <= cutoff
     uint32_t classMask;    // AND: include if (class & classMask) != 0
     int32_t depth;
+    uint32_t total;        // upper bound on the number of entries the rule lets through
+    uint32_t pad;
 };
 
 template <class Tp> __device__ __forceinline__ Tp rfl(Tp v) { return v; }
@@ -117,334 +119,7 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
     return lo;
 }
 
-// flags (uint16 per doc in LDS)
-//   AND : bits 0..7 count of ROLE_AND terms hit, bit 8 LOWEST hit, bit 9 S1, bit 10 S2
-//   DISJ: bits 0..7 (min rank + 1), 0 = not hit by a candidate-generating term
-//   PREFIX: bit 0 candidate
-#define F_LOWEST 0x100
-#define F_S1 0x200
-#define F_S2 0x400
-
-struct Arena {
-    int32_t* doc; float* score; uint8_t* cls;
-    unsigned long long* cursor; unsigned long long capacity;
-    uint2* blockOut;        // nq * nRanges : (offset low 32 | hi bits, count) — offset stored as 2x32 below
-    uint32_t* blockOutHi;
-    uint32_t* counts;       // nq * INFX_NCLASS
-    uint32_t* overflow;     // set to 1 when the arena would overflow
-    unsigned long long* algBytes;
-};
-
-template <int R>
-__global__ __launch_bounds__(WAVE) void k_accumulate(DevIndex ix, const DevQuery* __restrict__ queries,
-                                                      const DevTerm* __restrict__ terms, const int32_t* __restrict__ extraDocs,
-                                                      uint32_t nq, Arena ar) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* sScore = (float*)smem;                          // R
-    uint16_t* sFlag = (uint16_t*)(smem + (size_t)R * 4);   // R
-    uint32_t* sLo = (uint32_t*)(smem + (size_t)R * 6);     // INFX_MAX_QUERY_TERMS+1 (slice begin, relative to term begin)
-    uint32_t* sHi = sLo + (INFX_MAX_QUERY_TERMS + 1);
-    uint32_t* sHist = sHi + (INFX_MAX_QUERY_TERMS + 1);    // INFX_NCLASS
-
-    const int lane = threadIdx.x;
-    const uint32_t b = blockIdx.x;
-    const uint32_t q = b % nq;
-    const int r = (int)(b / nq);
-    const DevQuery Q = queries[q];
-    const int mode = Q.mode;
-    const int nT = (int)Q.numTerms;
-    const DevTerm* T = terms + Q.termOff;
-    const int32_t base = r * R;                                    // shard-local doc id of the range start
-    const int32_t rend = min(base + R, ix.N);
-    uint32_t outCount = 0; unsigned long long outOff = 0;
-
-    // ---- slice bounds of every term in this range, one lane per term ------------------------------------------
-    // (prefix set = pseudo term nT)
-    bool anyGen = false;
-    for (int t0 = 0; t0 <= nT; t0 += WAVE) {
-        int t = t0 + lane;
-        uint32_t lo = 0, hi = 0; bool gen = false;
-        if (t < nT) {
-            DevTerm tm = T[t];
-            if (tm.skip != 0xFFFFFFFFu) { lo = ix.skipTbl[tm.skip + r]; hi = ix.skipTbl[tm.skip + r + 1]; }
-            else {
-                const int32_t* arr = tm.isVirtual ? extraDocs : ix.postDoc;
-                lo = (uint32_t)(lower_bound_i32(arr, tm.begin, tm.end, base) - tm.begin);
-                hi = (uint32_t)(lower_bound_i32(arr, tm.begin + lo, tm.end, rend) - tm.begin);
-            }
-            if (mode == INFX_MODE_AND) gen = (tm.role & (INFX_ROLE_S1 | INFX_ROLE_S2)) != 0;
-            else if (mode == INFX_MODE_DISJ) gen = (tm.role & (INFX_ROLE_ELIGIBLE | INFX_ROLE_LOWQ)) != 0;
-            sLo[t] = lo; sHi[t] = hi;
-        } else if (t == nT) {
-            if (Q.prefixSet >= 0) {
-                uint64_t pb = ix.psOff[Q.prefixSet], pe = ix.psOff[Q.prefixSet + 1];
-                lo = (uint32_t)(lower_bound_i32(ix.psDocs, pb, pe, base) - pb);
-                hi = (uint32_t)(lower_bound_i32(ix.psDocs, pb + lo, pe, rend) - pb);
-                gen = (mode == INFX_MODE_PREFIX);
-            }
-            sLo[t] = lo; sHi[t] = hi;
-        }
-        if (__ballot(gen && hi > lo)) anyGen = true;
-    }
-    if (!anyGen) {   // range-granular skip: nothing here can become a candidate
-        if (lane == 0) { ar.blockOut[(uint64_t)q * ix.nRanges + r] = make_uint2(0, 0); ar.blockOutHi[(uint64_t)q * ix.nRanges + r] = 0; }
-        return;
-    }
-    for (int i = lane; i < R; i += WAVE) { sScore[i] = 0.f; sFlag[i] = 0; }
-    for (int i = lane; i < INFX_NCLASS; i += WAVE) sHist[i] = 0;
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS init visible to this wave's later accesses (single wave: program order)
-
-    // ---- PREFIX mode: mark the DocSet slice ---------------------------------------------------------------------
-    if (mode == INFX_MODE_PREFIX) {
-        uint64_t pb = ix.psOff[Q.prefixSet];
-        for (uint32_t i = sLo[nT] + lane; i < sHi[nT]; i += WAVE) sFlag[ix.psDocs[pb + i] - base] = 1;
-    }
-
-    // ---- stream every term once, in Bm25Scorer order (ascending termId) ----------------------------------------
-    unsigned long long myBytes = 0;
-    for (int t = 0; t < nT; t++) {
-        const uint32_t lo = sLo[t], hi = sHi[t];
-        if (hi <= lo) continue;
-        const DevTerm tm = T[t];
-        const float idf = tm.idf;
-        const uint8_t role = tm.role;
-        const uint16_t rk1 = (uint16_t)(tm.rank + 1);
-        const bool virt = tm.isVirtual != 0;
-        const int32_t* dptr = (virt ? extraDocs : ix.postDoc) + tm.begin;
-        const uint8_t* wptr = ix.postW + tm.begin;
-        if (lane == 0) myBytes += (unsigned long long)(hi - lo) * (virt ? 4u : 5u);
-        for (uint32_t i = lo + lane; i < hi; i += WAVE) {
-            int32_t doc = dptr[i];
-            float tf = virt ? 1.0f : (float)wptr[i];
-            int l = doc - base;
-            if (idf > 0.f) {     // Bm25Scorer.cs:301-309: terms with idf <= 0 are skipped by the scorer
-                float norm = ix.docNorm[doc];
-                float denom = tf + norm;
-                float core = (tf * (1.2f + 1.0f)) / denom;
-                float sc = idf * (core + 1.0f);
-                sScore[l] += sc;
-            }
-            if (mode == INFX_MODE_AND) {
-                uint16_t f = sFlag[l];
-                if (role & INFX_ROLE_AND) f = (uint16_t)((f & 0xFF00) | (((f & 0xFF) + 1) & 0xFF));
-                if (role & INFX_ROLE_LOWEST) f |= F_LOWEST;
-                if (role & INFX_ROLE_S1) f |= F_S1;
-                if (role & INFX_ROLE_S2) f |= F_S2;
-                sFlag[l] = f;
-            } else if (mode == INFX_MODE_DISJ) {
-                if (role & (INFX_ROLE_ELIGIBLE | INFX_ROLE_LOWQ)) {
-                    uint16_t f = sFlag[l];
-                    if (f == 0 || rk1 < f) sFlag[l] = rk1;
-                }
-            }
-        }
-    }
-
-    // ---- classify + count + compact ----------------------------------------------------------------------------------
-    const int nAnd = Q.nAnd;
-    // preseen set (non-PREFIX modes): docs whose upperBounds were pre-marked (TieredCandidateSelector.cs:74-77)
-    const uint64_t psb = (Q.prefixSet >= 0) ? ix.psOff[Q.prefixSet] : 0;
-    const uint32_t psLo = sLo[nT], psHi = sHi[nT];
-    // pass A: count emitted
-    uint32_t total = 0;
-    for (int i0 = 0; i0 < R; i0 += WAVE) {
-        int l = i0 + lane;
-        bool emit = false;
-        if (base + l < rend) {
-            uint16_t f = sFlag[l]; float sc = sScore[l];
-            if (sc > 0.f) {
-                if (mode == INFX_MODE_AND) emit = (f & (F_S1 | F_S2)) != 0;
-                else emit = f != 0;
-            }
-        }
-        total += __popcll(__ballot(emit));
-    }
-    if (total == 0) {
-        if (lane == 0) { ar.blockOut[(uint64_t)q * ix.nRanges + r] = make_uint2(0, 0); ar.blockOutHi[(uint64_t)q * ix.nRanges + r] = 0;
-                         atomicAdd(ar.algBytes, myBytes); }
-        return;
-    }
-    if (lane == 0) {
-        outOff = atomicAdd(ar.cursor, (unsigned long long)total);
-        if (outOff + total > ar.capacity) { atomicExch(ar.overflow, 1u); total = 0; }
-    }
-    outOff = rfl_u64(outOff); total = (uint32_t)rfl_i((int)total);
-    if (total == 0) { if (lane == 0) { ar.blockOut[(uint64_t)q * ix.nRanges + r] = make_uint2(0, 0); ar.blockOutHi[(uint64_t)q * ix.nRanges + r] = 0; } return; }
-    uint32_t w = 0;
-    for (int i0 = 0; i0 < R; i0 += WAVE) {
-        int l = i0 + lane;
-        bool emit = false; uint8_t cls = 0; float sc = 0.f;
-        if (base + l < rend) {
-            uint16_t f = sFlag[l]; sc = sScore[l];
-            if (sc > 0.f) {
-                if (mode == INFX_MODE_AND) {
-                    if (f & (F_S1 | F_S2)) {
-                        emit = true;
-                        int cnt = f & 0xFF;
-                        bool t1 = cnt == nAnd - 1;
-                        bool t0 = t1 && (f & F_LOWEST);
-                        cls = (uint8_t)((t0 ? 1 : 0) | ((t1 && nAnd >= 3) ? 2 : 0) | ((f & F_S1) ? 4 : 0) | ((f & F_S2) ? 8 : 0));
-                        atomicAdd(&sHist[cls], 1u);
-                    }
-                } else if (mode == INFX_MODE_DISJ) {
-                    if (f != 0) {
-                        emit = true;
-                        cls = (uint8_t)((f - 1) & 0x7F);
-                        bool pre = false;
-                        if (psHi > psLo) {
-                            int32_t d = base + l;
-                            uint64_t p = lower_bound_i32(ix.psDocs, psb + psLo, psb + psHi, d);
-                            pre = p < psb + psHi && ix.psDocs[p] == d;
-                        }
-                        if (pre) cls |= 0x80; else atomicAdd(&sHist[cls], 1u);
-                    }
-                } else {
-                    if (f != 0) { emit = true; cls = 1; atomicAdd(&sHist[1], 1u); }
-                }
-            }
-        }
-        unsigned long long m = __ballot(emit);
-        if (emit) {
-            uint32_t pos = w + __popcll(m & ((1ull << lane) - 1));
-            ar.doc[outOff + pos] = ix.docBase + base + l;
-            ar.score[outOff + pos] = sc;
-            ar.cls[outOff + pos] = cls;
-        }
-        w += __popcll(m);
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    for (int i = lane; i < INFX_NCLASS; i += WAVE) { uint32_t c = sHist[i]; if (c) atomicAdd(&ar.counts[(uint64_t)q * INFX_NCLASS + i], c); }
-    if (lane == 0) {
-        ar.blockOut[(uint64_t)q * ix.nRanges + r] = make_uint2((uint32_t)outOff, total);
-        ar.blockOutHi[(uint64_t)q * ix.nRanges + r] = (uint32_t)(outOff >> 32);
-        atomicAdd(ar.algBytes, myBytes + (unsigned long long)total * 12ull);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_select: one 256-thread block per query. Radix select on the 64-bit composite key
-//   (score bits << 32) | (0xFFFFFFFF - doc)   — descending — then LDS bitonic sort of the survivors.
-#define SEL_THREADS 256
-#define SEL_CAP 2048      // survivors sorted in LDS (>= max depth rounded up to a power of two)
-
-__device__ __forceinline__ bool sel_pass(const SelRule& rule, uint8_t c) {
-    if (rule.mode == INFX_MODE_AND) return (c & rule.classMask) != 0;
-    if (rule.mode == INFX_MODE_DISJ) return (int)(c & 0x7F) <= rule.cutoffRank;
-    return true;
-}
-
-__global__ __launch_bounds__(SEL_THREADS) void k_select(Arena ar, int nRanges, const SelRule* __restrict__ rules,
-                                                         infx_hit* __restrict__ out, uint32_t* __restrict__ outCount, int outStride) {
-    __shared__ uint32_t hist[4096];
-    __shared__ uint32_t part[SEL_THREADS];
-    __shared__ unsigned long long keys[SEL_CAP];
-    __shared__ uint32_t sCount, sBin, sRemain;
-    __shared__ unsigned long long sPrefix, sMask;
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const SelRule rule = rules[q];
-    const int depth = rule.depth;
-    const uint2* bo = ar.blockOut + (uint64_t)q * nRanges;
-    const uint32_t* boh = ar.blockOutHi + (uint64_t)q * nRanges;
-
-    // total filtered count
-    if (tid == 0) sCount = 0;
-    __syncthreads();
-    {
-        uint32_t local = 0;
-        for (int r = 0; r < nRanges; r++) {
-            uint2 e = bo[r]; if (e.y == 0) continue;
-            uint64_t off = ((uint64_t)boh[r] << 32) | e.x;
-            for (uint32_t i = tid; i < e.y; i += SEL_THREADS) if (sel_pass(rule, ar.cls[off + i])) local++;
-        }
-        atomicAdd(&sCount, local);
-    }
-    __syncthreads();
-    uint32_t totalFiltered = sCount;
-    // threshold search: find prefix such that #keys > prefix-range fits
-    unsigned long long prefix = 0, mask = 0;   // keys matching (key & mask) == prefix are "undecided"
-    uint32_t remain = (uint32_t)depth;         // how many still to take from the undecided set
-    uint32_t undecided = totalFiltered;
-    // 12-bit digits from the top: {sign,exp,3 mantissa}, {12 mantissa}, {8 mantissa + 4 id}, ... ; last digit 4 bits
-    int shift = 52, width = 12;
-    while ((uint32_t)depth - remain + undecided > (uint32_t)SEL_CAP && shift >= 0) {
-        const uint32_t nb = 1u << width, dm = nb - 1u;
-        for (uint32_t i = tid; i < nb; i += SEL_THREADS) hist[i] = 0;
-        __syncthreads();
-        for (int r = 0; r < nRanges; r++) {
-            uint2 e = bo[r]; if (e.y == 0) continue;
-            uint64_t off = ((uint64_t)boh[r] << 32) | e.x;
-            for (uint32_t i = tid; i < e.y; i += SEL_THREADS) {
-                if (!sel_pass(rule, ar.cls[off + i])) continue;
-                unsigned long long k = ((unsigned long long)__float_as_uint(ar.score[off + i]) << 32) | (0xFFFFFFFFu - (uint32_t)ar.doc[off + i]);
-                if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> shift) & dm], 1u);
-            }
-        }
-        __syncthreads();
-        // chunked suffix scan from the top bin: thread t owns bins [nb-16(t+1), nb-16t)
-        const uint32_t per = nb / SEL_THREADS ? nb / SEL_THREADS : 1;
-        uint32_t csum = 0;
-        if ((uint32_t)tid * per < nb) for (uint32_t j = 0; j < per; j++) csum += hist[nb - 1 - ((uint32_t)tid * per + j)];
-        part[tid] = csum;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t acc = 0; uint32_t c = 0;
-            uint32_t nchunks = nb / per;
-            for (; c < nchunks; c++) { if (acc + part[c] >= remain) break; acc += part[c]; }
-            if (c >= nchunks) c = nchunks - 1;
-            uint32_t bsel = 0;
-            for (uint32_t j = 0; j < per; j++) {
-                uint32_t bin = nb - 1 - (c * per + j);
-                if (acc + hist[bin] >= remain || j == per - 1) { bsel = bin; break; }
-                acc += hist[bin];
-            }
-            sBin = bsel; sRemain = remain - acc; sCount = hist[bsel];
-        }
-        __syncthreads();
-        // keys with a higher digit are all taken (gathered below via (k & mask) >= prefix); narrow the undecided set
-        prefix |= (unsigned long long)sBin << shift; mask |= (unsigned long long)dm << shift;
-        remain = sRemain; undecided = sCount;
-        if (shift == 4) { shift = 0; width = 4; } else if (shift == 0) shift = -1; else shift -= 12;
-        __syncthreads();
-    }
-    // gather: all keys strictly greater than the undecided range + the undecided keys themselves
-    // "greater": (k & mask) > prefix  (compare on the decided digits)
-    if (tid == 0) sCount = 0;
-    __syncthreads();
-    for (int r = 0; r < nRanges; r++) {
-        uint2 e = bo[r]; if (e.y == 0) continue;
-        uint64_t off = ((uint64_t)boh[r] << 32) | e.x;
-        for (uint32_t i = tid; i < e.y; i += SEL_THREADS) {
-            if (!sel_pass(rule, ar.cls[off + i])) continue;
-            unsigned long long k = ((unsigned long long)__float_as_uint(ar.score[off + i]) << 32) | (0xFFFFFFFFu - (uint32_t)ar.doc[off + i]);
-            if ((k & mask) >= prefix) { uint32_t p = atomicAdd(&sCount, 1u); if (p < SEL_CAP) keys[p] = k; }
-        }
-    }
-    __syncthreads();
-    uint32_t n = min(sCount, (uint32_t)SEL_CAP);
-    for (uint32_t i = n + tid; i < SEL_CAP; i += SEL_THREADS) keys[i] = 0ull;
-    __syncthreads();
-    // bitonic sort descending
-    for (uint32_t k = 2; k <= SEL_CAP; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < SEL_CAP; i += SEL_THREADS) {
-                uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    unsigned long long a = keys[i], b2 = keys[ixj];
-                    bool up = (i & k) == 0;   // descending in "up" blocks
-                    if (up ? (a < b2) : (a > b2)) { keys[i] = b2; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    uint32_t take = min(n, (uint32_t)depth);
-    for (uint32_t i = tid; i < take; i += SEL_THREADS) {
-        unsigned long long k = keys[i];
-        infx_hit h; h.doc = (int32_t)(0xFFFFFFFFu - (uint32_t)k); h.score = __uint_as_float((uint32_t)(k >> 32));
-        out[(uint64_t)q * outStride + i] = h;
-    }
-    if (tid == 0) outCount[q] = take;
-}
-
+#include "stage1.hip.inc"
 #include "stage2.hip.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -461,10 +136,12 @@ struct infx_stream {
     void* dHitCount = nullptr; size_t capHitCount = 0;
     void* dBlockOut = nullptr; size_t capBlockOut = 0;
     void* dBlockOutHi = nullptr; size_t capBlockOutHi = 0;
+    void* dQBytes = nullptr; size_t capQBytes = 0;
     void* dCounts = nullptr; size_t capCounts = 0;
     void* dCovQ = nullptr; size_t capCovQ = 0;
     void* dCovC = nullptr; size_t capCovC = 0;
     void* dCovO = nullptr; size_t capCovO = 0;
+    void* dCovF = nullptr; size_t capCovF = 0;
     int32_t* arDoc = nullptr; float* arScore = nullptr; uint8_t* arCls = nullptr; size_t arCap = 0;
     unsigned long long* dCursor = nullptr;   // [0]=cursor [1]=algBytes
     uint32_t* dOverflow = nullptr;
@@ -484,11 +161,11 @@ static int32_t grow(void** p, size_t* cap, size_t need) {
 }
 #define GROW(p, cap, need) do { int32_t rc_ = grow((void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)
 
-template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar) {
-    size_t lds = (size_t)R * 6 + (size_t)(INFX_MAX_QUERY_TERMS + 1) * 8 + INFX_NCLASS * 4;
+template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT) {
+    size_t lds = (size_t)(R / 32) * 8 + (size_t)ACC_CAP * 8 + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
     uint64_t blocks = (uint64_t)nq * s->ix->d.nRanges;
     k_accumulate<R><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, nq, ar);
+                                                                           (const int32_t*)s->dExtra, nq, ar, maxT);
 }
 
 extern "C" {
@@ -504,8 +181,8 @@ int32_t infx_create(const infx_config* cfg, infx_index** out) {
     HIPCHK(hipSetDevice(cfg->device));
     infx_index* ix = new infx_index();
     ix->cfg = *cfg;
-    int R = cfg->range_docs ? cfg->range_docs : 2048;
-    if (R != 512 && R != 1024 && R != 2048 && R != 4096 && R != 8192) { delete ix; return fail(INFX_EINVAL, "range_docs must be a power of two in [512, 8192]%s"); }
+    int R = cfg->range_docs ? cfg->range_docs : 1024;
+    if (R != 512 && R != 1024 && R != 2048 && R != 4096 && R != 8192 && R != 16384) { delete ix; return fail(INFX_EINVAL, "range_docs must be a power of two in [512, 16384]%s"); }
     ix->d.R = R; ix->d.rshift = __builtin_ctz(R);
     if (ix->cfg.max_depth <= 0) ix->cfg.max_depth = 500;
     if (ix->cfg.max_depth > SEL_CAP / 2) { delete ix; return fail(INFX_EINVAL, "max_depth too large%s"); }
@@ -616,8 +293,8 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
 void infx_stream_destroy(infx_stream* s) {
     if (!s) return;
     hipSetDevice(s->ix->cfg.device);
-    void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dCounts,
-                  s->dCovQ, s->dCovC, s->dCovO, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow};
+    void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dCounts,
+                  s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow};
     for (void* p : ps) if (p) hipFree(p);
     hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1};
     for (auto e : ev) hipEventDestroy(e);
@@ -635,7 +312,8 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     if ((uint64_t)nq * ix->d.nRanges > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nq * nRanges exceeds the grid limit; split the batch%s");
     // translate + capacity bound
     std::vector<DevQuery> dq(nq); std::vector<DevTerm> dt(nterms);
-    unsigned long long bound = 0;
+    std::vector<unsigned long long> qbase((size_t)nq + 1);
+    unsigned long long bound = 0; int maxT = 1;
     for (uint32_t i = 0; i < nq; i++) {
         const infx_query& Q = q[i];
         if (Q.num_terms > INFX_MAX_QUERY_TERMS || (uint64_t)Q.term_off + Q.num_terms > nterms) return fail(INFX_EINVAL, "bad term range%s");
@@ -643,6 +321,7 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
         if (Q.mode < INFX_MODE_PREFIX || Q.mode > INFX_MODE_AND) return fail(INFX_EINVAL, "bad query mode%s");
         if (Q.prefix_set >= (int32_t)ix->d.nSets || (Q.mode == INFX_MODE_PREFIX && Q.prefix_set < 0)) return fail(INFX_EINVAL, "bad prefix set%s");
         dq[i] = DevQuery{Q.term_off, Q.num_terms, Q.mode, Q.prefix_set, Q.depth, Q.n_and};
+        maxT = std::max(maxT, (int)Q.num_terms);
         unsigned long long qb = 0;
         for (uint32_t k = 0; k < Q.num_terms; k++) {
             const infx_term& tm = terms[Q.term_off + k];
@@ -661,13 +340,10 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
             if (gen) qb += D.end - D.begin;
         }
         if (Q.mode == INFX_MODE_PREFIX) qb = ix->hPsOff[Q.prefix_set + 1] - ix->hPsOff[Q.prefix_set];
+        qbase[i] = bound;
         bound += std::min<unsigned long long>(qb, (unsigned long long)ix->d.N);
     }
-    // skip-table bases (same rule as infx_upload_postings)
-    {
-        // recompute lazily: a host mirror of skipIdx
-        static thread_local std::vector<uint32_t> dummy;
-    }
+    qbase[nq] = bound;
     // arena
     size_t need = (size_t)bound + 64;
     if (need > s->arCap) {
@@ -681,8 +357,9 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     GROW(s->dQueries, s->capQueries, nq * sizeof(DevQuery));
     GROW(s->dTerms, s->capTerms, std::max<size_t>(1, nterms) * sizeof(DevTerm));
     GROW(s->dExtra, s->capExtra, std::max<size_t>(1, extra_n) * 4);
-    GROW(s->dBlockOut, s->capBlockOut, (size_t)nq * ix->d.nRanges * sizeof(uint2));
-    GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * ix->d.nRanges * 4);
+    GROW(s->dBlockOut, s->capBlockOut, ((size_t)nq + 1) * 8);      // qBase
+    GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * 4);        // qCursor
+    GROW(s->dQBytes, s->capQBytes, (size_t)nq * 8);
     GROW(s->dCounts, s->capCounts, (size_t)nq * INFX_NCLASS * 4);
     // skip bases need the device skipIdx: fetch once per index into a host mirror
     static std::mutex mu; static std::vector<std::pair<infx_index*, std::vector<uint32_t>>> mirrors;
@@ -701,35 +378,38 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     HIPCHK(hipMemcpyAsync(s->dQueries, dq.data(), nq * sizeof(DevQuery), hipMemcpyHostToDevice, s->st));
     if (nterms) HIPCHK(hipMemcpyAsync(s->dTerms, dt.data(), nterms * sizeof(DevTerm), hipMemcpyHostToDevice, s->st));
     if (extra_n) HIPCHK(hipMemcpyAsync(s->dExtra, extra_docs, (size_t)extra_n * 4, hipMemcpyHostToDevice, s->st));
-    HIPCHK(hipMemsetAsync(s->dCursor, 0, 16, s->st));
+    HIPCHK(hipMemcpyAsync(s->dBlockOut, qbase.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemsetAsync(s->dQBytes, 0, (size_t)nq * 8, s->st));
     HIPCHK(hipMemsetAsync(s->dOverflow, 0, 4, s->st));
     HIPCHK(hipMemsetAsync(s->dCounts, 0, (size_t)nq * INFX_NCLASS * 4, s->st));
-    Arena ar{s->arDoc, s->arScore, s->arCls, s->dCursor, (unsigned long long)s->arCap, (uint2*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
-             (uint32_t*)s->dCounts, s->dOverflow, s->dCursor + 1};
+    HIPCHK(hipMemsetAsync(s->dBlockOutHi, 0, (size_t)nq * 4, s->st));
+    Arena ar{s->arDoc, s->arScore, s->arCls, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
+             (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes};
     HIPCHK(hipEventRecord(s->evA0, s->st));
     switch (ix->d.R) {
-        case 512: launch_acc<512>(s, nq, ar); break;
-        case 1024: launch_acc<1024>(s, nq, ar); break;
-        case 2048: launch_acc<2048>(s, nq, ar); break;
-        case 4096: launch_acc<4096>(s, nq, ar); break;
-        default: launch_acc<8192>(s, nq, ar); break;
+        case 512: launch_acc<512>(s, nq, ar, maxT); break;
+        case 1024: launch_acc<1024>(s, nq, ar, maxT); break;
+        case 2048: launch_acc<2048>(s, nq, ar, maxT); break;
+        case 4096: launch_acc<4096>(s, nq, ar, maxT); break;
+        case 8192: launch_acc<8192>(s, nq, ar, maxT); break;
+        default: launch_acc<16384>(s, nq, ar, maxT); break;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evA1, s->st));
     s->timedAcc = true;
-    uint32_t ovf = 0; unsigned long long cur[2] = {0, 0};
+    uint32_t ovf = 0; std::vector<unsigned long long> qbytes(nq);
     if (counts_out) HIPCHK(hipMemcpyAsync(counts_out, s->dCounts, (size_t)nq * INFX_NCLASS * 4, hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipMemcpyAsync(&ovf, s->dOverflow, 4, hipMemcpyDeviceToHost, s->st));
-    HIPCHK(hipMemcpyAsync(cur, s->dCursor, 16, hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipMemcpyAsync(qbytes.data(), s->dQBytes, (size_t)nq * 8, hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));
     if (ovf) return fail(INFX_ECAPACITY, "candidate arena overflow (bound violated)%s");
-    s->lastAlgBytes = cur[1];
+    s->lastAlgBytes = 0; for (auto b : qbytes) s->lastAlgBytes += b;
     s->lastQ.assign(q, q + nq); s->lastNq = nq;
     return INFX_OK;
 }
 
 // TieredCandidateSelector tier rules evaluated from class counts (see header of this file / DESIGN.md)
-static SelRule make_rule(const infx_query& Q, const uint32_t* c) {
+static SelRule make_rule0(const infx_query& Q, const uint32_t* c) {
     SelRule r{}; r.mode = Q.mode; r.depth = Q.depth; r.cutoffRank = 127; r.classMask = 0xFFFFFFFFu;
     const long k = Q.depth;
     if (Q.mode == INFX_MODE_AND) {
@@ -762,6 +442,16 @@ static SelRule make_rule(const infx_query& Q, const uint32_t* c) {
     return r;
 }
 
+static SelRule make_rule(const infx_query& Q, const uint32_t* c) {
+    SelRule r = make_rule0(Q, c);
+    unsigned long long tot = 0;
+    if (Q.mode == INFX_MODE_AND) { for (int i = 0; i < 16; i++) if (i & r.classMask) tot += c[i]; }
+    else if (Q.mode == INFX_MODE_DISJ) { for (int i = 0; i <= r.cutoffRank && i < 128; i++) tot += c[i]; tot += 128; /* pre-seen docs (< 100) are not in the histogram */ }
+    else tot = c[1];
+    r.total = (uint32_t)std::min<unsigned long long>(tot, 0xFFFFFFFFull); r.pad = 0;
+    return r;
+}
+
 int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* counts, infx_hit* out, uint32_t* out_count) {
     if (!s || !counts || !out || !out_count) return fail(INFX_EINVAL, "null argument%s");
     if (nq == 0) return INFX_OK;
@@ -775,8 +465,8 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     GROW(s->dHits, s->capHits, (size_t)nq * maxDepth * sizeof(infx_hit));
     GROW(s->dHitCount, s->capHitCount, (size_t)nq * 4);
     HIPCHK(hipMemcpyAsync(s->dRules, rules.data(), nq * sizeof(SelRule), hipMemcpyHostToDevice, s->st));
-    Arena ar{s->arDoc, s->arScore, s->arCls, s->dCursor, (unsigned long long)s->arCap, (uint2*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
-             (uint32_t*)s->dCounts, s->dOverflow, s->dCursor + 1};
+    Arena ar{s->arDoc, s->arScore, s->arCls, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
+             (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes};
     HIPCHK(hipEventRecord(s->evS0, s->st));
     k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth);
     HIPCHK(hipGetLastError());
@@ -800,7 +490,7 @@ int32_t infx_stage1_batch(infx_stream* s, uint32_t nq, const infx_query* q, uint
 }
 
 int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, uint32_t ncand, const infx_cov_cand* cand,
-                          infx_cov_out* out, int32_t want_features) {
+                          infx_cov_out* out, int32_t* feat_out) {
     if (!s || (ncand && (!q || !cand || !out))) return fail(INFX_EINVAL, "null argument%s");
     if (ncand == 0) return INFX_OK;
     infx_index* ix = s->ix;
@@ -812,15 +502,17 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     GROW(s->dCovQ, s->capCovQ, (size_t)nq * sizeof(infx_cov_query));
     GROW(s->dCovC, s->capCovC, (size_t)ncand * sizeof(infx_cov_cand));
     GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
+    if (feat_out) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
     HIPCHK(hipMemcpyAsync(s->dCovQ, q, (size_t)nq * sizeof(infx_cov_query), hipMemcpyHostToDevice, s->st));
     HIPCHK(hipMemcpyAsync(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand), hipMemcpyHostToDevice, s->st));
     HIPCHK(hipEventRecord(s->evC0, s->st));
     k_stage2<<<(ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st>>>(ix->d, (const infx_cov_query*)s->dCovQ, nq,
-                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, want_features);
+                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
     s->timedCov = true;
     HIPCHK(hipMemcpyAsync(out, s->dCovO, (size_t)ncand * sizeof(infx_cov_out), hipMemcpyDeviceToHost, s->st));
+    if (feat_out) HIPCHK(hipMemcpyAsync(feat_out, s->dCovF, (size_t)ncand * INFX_NFEAT * 4, hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));
     return INFX_OK;
 }
