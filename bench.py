@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--range-docs", type=int, default=0)
     ap.add_argument("--build-threads", type=int, default=0)
+    ap.add_argument("--sessions", type=int, default=3, help="batches in flight (host threads, one engine session each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU-baseline sample (0 = auto, ~10-30 s)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -52,7 +53,7 @@ def main():
         dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
     from tools.synth import Synth, CONFIGS
-    from infidex_amd import SearchEngine, build as _build
+    from infidex_amd import SearchEngine, Session, build as _build
     _build.build()
 
     ncpu = os.cpu_count() or 8
@@ -100,20 +101,48 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # A stream of batches: `--sessions` host threads, each with its own engine session (HIP stream + scratch), pull batches from
+    # a shared cursor, so the host-side preparation of one batch overlaps the GPU stages of another.  Every batch still runs the
+    # complete hot path; results do not depend on the interleaving (tests/test_gpu_parity.py::test_batching_is_transparent).
+    nsess = max(1, min(args.sessions, args.steps))
+    sessions = [Session(eng) for _ in range(nsess)]
     for s in range(args.warmup):
-        eng.search_packed(batches[s][0], batches[s][1], k, 500)
+        sessions[s % nsess].search_packed(batches[s][0], batches[s][1], k, 500)
     sync()
+    tim = [None] * nsteps
+    lat = [0.0] * nsteps
+    results = [None] * nsteps
+    cursor = {"next": args.warmup}
+    lock = threading.Lock()
+    errors = []
+
+    def worker(sess):
+        try:
+            while True:
+                with lock:
+                    s = cursor["next"]
+                    if s >= nsteps:
+                        return
+                    cursor["next"] = s + 1
+                ts = time.time()
+                keys, scores, ties, counts, flags = sess.search_packed(batches[s][0], batches[s][1], k, 500)
+                lat[s] = (time.time() - ts) * 1000.0
+                tim[s] = sess.last_timings()
+                results[s] = (keys, counts)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
     t_start = time.time()
-    tim = []
-    lat = []
-    first_keys = None
-    for s in range(args.warmup, nsteps):
-        ts = time.time()
-        keys, scores, ties, counts, flags = eng.search_packed(batches[s][0], batches[s][1], k, 500)
-        lat.append((time.time() - ts) * 1000.0)
-        tim.append(eng.last_timings())
-        if first_keys is None:
-            first_keys = (keys.copy(), counts.copy())
+    ths = [threading.Thread(target=worker, args=(se,)) for se in sessions]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errors:
+        raise errors[0]
+    tim = tim[args.warmup:]
+    lat = lat[args.warmup:]
+    first_keys = (results[args.warmup][0].copy(), results[args.warmup][1].copy())
     sync()
     elapsed = time.time() - t_start
     if dist is not None:
@@ -124,8 +153,14 @@ def main():
     total_queries = args.steps * args.batch * world     # replicas: every rank answers its own query stream
     qps = total_queries / elapsed
 
-    acc_ms = float(np.mean([t["k_accumulate_ms"] for t in tim]))
-    alg = float(np.mean([t["alg_bytes"] for t in tim]))
+    # roofline leg: the same batches once more on ONE session (no concurrent kernels), HIP events on the launch stream
+    roof = []
+    for s in range(args.warmup, min(nsteps, args.warmup + 3)):
+        sessions[0].search_packed(batches[s][0], batches[s][1], k, 500)
+        roof.append(sessions[0].last_timings())
+    acc_ms = float(np.mean([t["k_accumulate_ms"] for t in roof]))
+    alg = float(np.mean([t["alg_bytes"] for t in roof]))
+    streamed = float(np.mean([t["streamed_bytes"] for t in roof]))
     achieved = alg / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
     out = {
         "metric": "queries/sec, 10M-doc corpus, top-k=20 (whole hot path, index resident in HBM)",
@@ -135,13 +170,18 @@ def main():
         "config": {"workload": f"BASELINE config {args.config}: {syn.cfg['docs']} docs, vocab {syn.cfg['vocab']}, {args.batch}-query batches, "
                                f"2-3 word queries {int(syn.cfg['fuzz'] * 100)}% fuzzed, depth 500, top-{k}",
                    "docs": syn.cfg["docs"], "batch": args.batch, "top_k": k, "coverage_depth": 500,
+                   "sessions_in_flight": nsess,
                    "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (one index per GPU, query stream split)"},
         "p50_batch_latency_ms": float(np.median(lat)),
         "stage_ms_per_step": {kk: float(np.mean([t[kk] for t in tim])) for kk in ("plan_ms", "stage1_ms", "prep2_ms", "stage2_ms", "post_ms",
                                                                                   "k_accumulate_ms", "k_select_ms", "k_stage2_ms")},
         "roofline": {"kernel": "k_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": acc_ms},
+                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": acc_ms,
+                     "streamed_bytes_per_launch": streamed, "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
+                     "other_kernels_ms": {"k_select": float(np.mean([t["k_select_ms"] for t in roof])), "k_stage2": float(np.mean([t["k_stage2_ms"] for t in roof]))},
+                     "note": "achieved = SURVEY 8(d) algorithmic bytes / k_accumulate duration (HIP events, uncontended launch); ranges without "
+                             "candidates are skipped, so fewer bytes are streamed than the algorithm nominally reads"},
         "setup_s": {"corpus_gen": t_gen, "index_build_and_upload": t_index, "host_threads": bthreads},
     }
     if want_cpu:

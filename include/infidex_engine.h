@@ -47,9 +47,21 @@ int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_
                                  int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                  uint32_t* out_counts, uint32_t* out_flags);
 
+/* Sessions: one in-flight batch each (own HIP stream + scratch). Calling infx_engine_session_search_batch from several host
+ * threads, one session per thread, overlaps the host preparation of one batch with the GPU stages of another — the
+ * reference's concurrent-reader model (ReaderWriterLockSlim read lock, SearchEngine.cs:33,258). */
+typedef struct infx_session infx_session;
+int32_t infx_engine_session_create(infx_engine* e, infx_session** out);
+void    infx_engine_session_destroy(infx_session* s);
+int32_t infx_engine_session_search_batch(infx_session* s, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
+                                         int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
+                                         uint32_t* out_counts, uint32_t* out_flags);
+int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, float* kernel_ms3, uint64_t* alg3);
+
 /* host_ms5: plan, stage1 (incl. transfers), stage-2 prep, stage2 (incl. transfers), final ordering;
  * kernel_ms3: accumulate, select, stage2 kernel durations from HIP events on the launch stream;
- * alg3: algorithmic bytes of the accumulate launch, Stage-2 candidate count, Stage-2 text bytes. */
+ * alg (5 entries): algorithmic bytes of the accumulate launch per SURVEY 8(d), Stage-2 candidate count, Stage-2 text bytes,
+ * bytes the accumulate launch actually streamed, Stage-1 candidates. */
 int32_t infx_engine_last_timings(infx_engine* e, double* host_ms5, float* kernel_ms3, uint64_t* alg3);
 
 /* ---- introspection used by the parity tests (host logic runs without a GPU) ---- */

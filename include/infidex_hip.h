@@ -169,9 +169,11 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
 /* Durations (ms) of the last Stage-1 accumulate / select / Stage-2 launches on this stream, from HIP events recorded on
  * the stream the kernels ran on. */
 int32_t infx_last_timings(infx_stream* s, float* accumulate_ms, float* select_ms, float* stage2_ms);
-/* Algorithmic bytes of the last accumulate launch: sum over (query, term) of posting bytes actually streamed
- * (5 B/posting, 4 B for virtual terms) + 4 B per emitted candidate norm gather + 8 B per emitted hit. */
+/* Bytes the last accumulate launch actually streamed (posting slices of the doc ranges that held candidates: 5 B/posting,
+ * 4 B for virtual terms, + 12 B per emitted arena entry) — an implementation figure, <= the algorithmic bytes of SURVEY 8(d). */
 int32_t infx_last_alg_bytes(infx_stream* s, uint64_t* bytes);
+/* Sum over the batch of card(C_q): candidates the tier rules let through (upper bound +128/query in disjunctive mode). */
+int32_t infx_last_candidates(infx_stream* s, uint64_t* n);
 
 #ifdef __cplusplus
 }

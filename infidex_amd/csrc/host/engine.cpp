@@ -28,22 +28,29 @@ inline int cmp_entry(const Entry& a, const Entry& b) {    // ScoreEntry.CompareT
 }
 }
 
-struct infx_engine {
-    HostIndex ix;
-    infx_engine_config cfg{};
-    infx_index* dev = nullptr;
+// One in-flight batch: its own HIP stream + scratch. Several sessions on one engine let the host preparation of one batch
+// overlap the GPU stages of another (SearchEngine.Search is callable from many threads concurrently, SearchEngine.cs:258).
+struct infx_session {
+    infx_engine* e = nullptr;
     infx_stream* stream = nullptr;
-    bool indexed = false;
-    FuzzyCache fuzzy;
-    std::unordered_map<int64_t, int32_t> keyToFirst;
-    bool keysAreIds = false;
     double tPrep1 = 0, tStage1 = 0, tPrep2 = 0, tStage2 = 0, tPost = 0;
-    float msAcc = 0, msSel = 0, msCov = 0; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0;
-    int threads = 1;
+    float msAcc = 0, msSel = 0, msCov = 0; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0;
     // last-batch introspection for parity tests
     std::vector<QueryPlan> lastPlans;
     std::vector<infx_hit> lastHits; std::vector<uint32_t> lastHitCount; int lastStride = 0;
     std::vector<infx_cov_cand> lastCands; std::vector<infx_cov_out> lastOuts; std::vector<int32_t> lastFeat;
+};
+
+struct infx_engine {
+    HostIndex ix;
+    infx_engine_config cfg{};
+    infx_index* dev = nullptr;
+    bool indexed = false;
+    FuzzyCache fuzzy;
+    std::unordered_map<int64_t, int32_t> keyToFirst;
+    bool keysAreIds = false;
+    int threads = 1;
+    infx_session* def = nullptr;      // default session (single-caller API)
 };
 
 extern "C" {
@@ -65,12 +72,15 @@ int32_t infx_engine_create(const infx_engine_config* cfg, infx_engine** out) {
         int32_t rc = infx_create(&dc, &e->dev);
         if (rc) { g_eerr = infx_last_error(); delete e; return rc; }
     }
+    e->def = new infx_session(); e->def->e = e;
     *out = e; return INFX_OK;
 }
 
 void infx_engine_destroy(infx_engine* e) {
     if (!e) return;
-    if (e->stream) infx_stream_destroy(e->stream);
+    infx_session* S = e->def;
+    if (S && S->stream) infx_stream_destroy(S->stream);
+    delete S;
     if (e->dev) infx_destroy(e->dev);
     delete e;
 }
@@ -90,7 +100,7 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
         int32_t rc = infx_upload_docs(e->dev, (uint32_t)ix.N, ix.docLen.data(), ix.avgdl, ix.docKey.data(), ix.textOff.data(), (const uint16_t*)ix.text.data());
         if (!rc) rc = infx_upload_postings(e->dev, (uint32_t)ix.terms.K(), ix.terms.off.data(), ix.terms.doc.data(), ix.terms.w.data(), ix.df.data());
         if (!rc) rc = infx_upload_prefix_docsets(e->dev, (uint32_t)(ix.psOff.size() - 1), ix.psOff.data(), ix.psDocs.data());
-        if (!rc) rc = infx_stream_create(e->dev, &e->stream);
+        if (!rc) rc = infx_stream_create(e->dev, &e->def->stream);
         if (rc) { g_eerr = infx_last_error(); return rc; }
     }
     e->indexed = true;
@@ -104,46 +114,67 @@ static int32_t key_to_id(infx_engine* e, int64_t key) {
 
 // SearchEngine.Search for a batch of queries (each = one reference Search call; results are independent of batching).
 // out_* are nq x max_results; out_flags: bit0 unsupported (short-query path), bit1 coverage stage ran, bit2 fell back to Stage 1
-int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
+static int32_t search_batch_impl(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
                                  int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                  uint32_t* out_counts, uint32_t* out_flags) {
     if (!e || (nq && (!q_arena || !q_offs || !out_keys || !out_scores || !out_counts)) || max_results < 1) return efail(INFX_EINVAL, "bad arguments");
     if (!e->indexed) { for (uint32_t i = 0; i < nq; i++) out_counts[i] = 0; return INFX_OK; }   // Result.MakeEmptyResult(), SearchEngine.cs:261-262
-    if (!e->dev || !e->stream) return efail(INFX_EHIP, "no GPU: the scoring hot path has no CPU fallback");
+    if (!e->dev || !S || !S->stream) return efail(INFX_EHIP, "no GPU: the scoring hot path has no CPU fallback");
     if (depth <= 0 || depth > e->ix.cfg.maxDepth) return efail(INFX_EINVAL, "CoverageDepth exceeds the engine's max_depth");
     const HostIndex& ix = e->ix;
     const int threads = e->threads;
     g_eerr.clear();
     double t0 = now_ms();
     // ---------------- Stage-1 planning (host, parallel over queries) ----------------
-    std::vector<QueryPlan>& plans = e->lastPlans; plans.assign(nq, QueryPlan());
+    std::vector<QueryPlan>& plans = S->lastPlans; plans.assign(nq, QueryPlan());
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; i++) plan_stage1(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i]);
     });
     double tPlanPar = now_ms() - t0;
     std::vector<infx_query> dq; std::vector<infx_term> dterms; std::vector<int32_t> extra; std::vector<uint32_t> qmap;   // device batch -> query index
-    for (uint32_t i = 0; i < nq; i++) {
-        QueryPlan& P = plans[i];
-        if (P.blank || P.unsupported || P.noTerms) continue;
-        P.q.term_off = (uint32_t)dterms.size();
-        for (size_t k = 0; k < P.terms.size(); k++) {
-            infx_term t = P.terms[k];
-            if (t.term_id < 0) { t.extra_off = (uint32_t)extra.size(); extra.insert(extra.end(), P.fuzzy[k]->docs.begin(), P.fuzzy[k]->docs.end()); }
-            dterms.push_back(t);
+    {
+        size_t nterm = 0, nextra = 0;
+        std::vector<size_t> termBase(nq), extraBase(nq);
+        for (uint32_t i = 0; i < nq; i++) {
+            QueryPlan& P = plans[i];
+            termBase[i] = nterm; extraBase[i] = nextra;
+            if (P.blank || P.unsupported || P.noTerms) continue;
+            P.q.term_off = (uint32_t)nterm; nterm += P.terms.size();
+            for (size_t k = 0; k < P.terms.size(); k++) if (P.terms[k].term_id < 0) nextra += P.fuzzy[k]->docs.size();
+            dq.push_back(P.q); qmap.push_back(i);
         }
-        dq.push_back(P.q); qmap.push_back(i);
+        if (nextra > 0xFFFFFFF0ull) return efail(INFX_ECAPACITY, "fuzzy unions of this batch exceed 2^32 postings; split the batch");
+        dterms.resize(nterm); extra.resize(nextra);
+        parallel_dyn(nq, threads, 8, [&](int64_t b, int64_t en, int) {
+            for (int64_t i = b; i < en; i++) {
+                QueryPlan& P = plans[i];
+                if (P.blank || P.unsupported || P.noTerms) continue;
+                size_t xo = extraBase[i];
+                for (size_t k = 0; k < P.terms.size(); k++) {
+                    infx_term t = P.terms[k];
+                    if (t.term_id < 0) { const auto& d = P.fuzzy[k]->docs; t.extra_off = (uint32_t)xo; std::memcpy(extra.data() + xo, d.data(), d.size() * 4); xo += d.size(); }
+                    dterms[termBase[i] + k] = t;
+                }
+            }
+        });
     }
     double t1 = now_ms();
     // ---------------- Stage 1 on the GPU ----------------
     const uint32_t nd = (uint32_t)dq.size();
-    std::vector<infx_hit>& hits = e->lastHits; std::vector<uint32_t>& hitCount = e->lastHitCount;
-    hits.assign((size_t)nd * depth, infx_hit{0, 0.f}); hitCount.assign(nd, 0); e->lastStride = depth;
-    e->msAcc = e->msSel = e->msCov = 0; e->algBytes = 0;
+    std::vector<infx_hit>& hits = S->lastHits; std::vector<uint32_t>& hitCount = S->lastHitCount;
+    hits.assign((size_t)nd * depth, infx_hit{0, 0.f}); hitCount.assign(nd, 0); S->lastStride = depth;
+    S->msAcc = S->msSel = S->msCov = 0; S->algBytes = 0;
     if (nd) {
-        int32_t rc = infx_stage1_batch(e->stream, nd, dq.data(), (uint32_t)dterms.size(), dterms.data(), (uint32_t)extra.size(), extra.data(), hits.data(), hitCount.data());
+        int32_t rc = infx_stage1_batch(S->stream, nd, dq.data(), (uint32_t)dterms.size(), dterms.data(), (uint32_t)extra.size(), extra.data(), hits.data(), hitCount.data());
         if (rc) { g_eerr = infx_last_error(); return rc; }
-        infx_last_timings(e->stream, &e->msAcc, &e->msSel, nullptr);
-        infx_last_alg_bytes(e->stream, &e->algBytes);
+        infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
+        infx_last_alg_bytes(S->stream, &S->streamedBytes);
+        infx_last_candidates(S->stream, &S->s1Candidates);
+        // B_alg(q) = sum_t df_t * 5 B (4 B for fuzzy virtual terms) + card(C_q) * 4 B + depth * 12 B
+        uint64_t ab = 0;
+        for (auto& t : dterms) ab += t.term_id >= 0 ? (uint64_t)ix.terms.len((uint32_t)t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
+        uint64_t nh = 0; for (uint32_t c : hitCount) nh += c;
+        S->algBytes = ab + S->s1Candidates * 4ull + nh * 12ull;
     }
     double t2 = now_ms();
     // ---------------- Stage-2 preparation (host) ----------------
@@ -212,7 +243,7 @@ int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_
         }
     });
     for (uint32_t i = 0; i < nq; i++) if (covErr[i]) return efail(covErr[i], "query exceeds the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length)");
-    std::vector<infx_cov_query> covBatch; std::vector<infx_cov_cand>& cands = e->lastCands; cands.clear();
+    std::vector<infx_cov_query> covBatch; std::vector<infx_cov_cand>& cands = S->lastCands; cands.clear();
     for (uint32_t i = 0; i < nq; i++) {
         PerQ& S = pq[i];
         if (!S.runCov) continue;
@@ -222,14 +253,14 @@ int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_
     }
     double t3 = now_ms();
     // ---------------- Stage 2 on the GPU ----------------
-    std::vector<infx_cov_out>& outs = e->lastOuts; outs.assign(cands.size(), infx_cov_out{});
-    e->s2Candidates = cands.size(); e->s2TextBytes = 0;
-    for (auto& c : cands) e->s2TextBytes += 2 * (ix.textOff[c.doc + 1] - ix.textOff[c.doc]);
-    if (e->cfg.want_features) e->lastFeat.assign(cands.size() * INFX_NFEAT, 0);
+    std::vector<infx_cov_out>& outs = S->lastOuts; outs.assign(cands.size(), infx_cov_out{});
+    S->s2Candidates = cands.size(); S->s2TextBytes = 0;
+    for (auto& c : cands) S->s2TextBytes += 2 * (ix.textOff[c.doc + 1] - ix.textOff[c.doc]);
+    if (e->cfg.want_features) S->lastFeat.assign(cands.size() * INFX_NFEAT, 0);
     if (!cands.empty()) {
-        int32_t rc = infx_stage2_batch(e->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)cands.size(), cands.data(), outs.data(), e->cfg.want_features ? e->lastFeat.data() : nullptr);
+        int32_t rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)cands.size(), cands.data(), outs.data(), e->cfg.want_features ? S->lastFeat.data() : nullptr);
         if (rc) { g_eerr = infx_last_error(); return rc; }
-        infx_last_timings(e->stream, nullptr, nullptr, &e->msCov);
+        infx_last_timings(S->stream, nullptr, nullptr, &S->msCov);
         for (auto& o : outs) if (o.status) return efail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)");
     }
     double t4 = now_ms();
@@ -291,15 +322,45 @@ int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_
                 nq, nd, dterms.size(), extra.size(), cands.size(), t1 - t0, tPlanPar, t2 - t1, t3 - t2, t4 - t3, t5 - t4,
                 (long long)e->fuzzy.fuzzyCalls.exchange(0), e->fuzzy.fuzzyNs.exchange(0) / 1e6, e->fuzzy.ld1Ns.exchange(0) / 1e6, (long long)e->fuzzy.fuzzyDocs.exchange(0));
     }
-    e->tPrep1 = t1 - t0; e->tStage1 = t2 - t1; e->tPrep2 = t3 - t2; e->tStage2 = t4 - t3; e->tPost = t5 - t4;
+    S->tPrep1 = t1 - t0; S->tStage1 = t2 - t1; S->tPrep2 = t3 - t2; S->tStage2 = t4 - t3; S->tPost = t5 - t4;
+    return INFX_OK;
+}
+
+int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
+                                 int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
+                                 uint32_t* out_counts, uint32_t* out_flags) {
+    if (!e) return efail(INFX_EINVAL, "null engine");
+    return search_batch_impl(e, e->def, nq, q_arena, q_offs, max_results, depth, enable_coverage, out_keys, out_scores, out_ties, out_counts, out_flags);
+}
+int32_t infx_engine_session_create(infx_engine* e, infx_session** out) {
+    if (!e || !out) return efail(INFX_EINVAL, "null");
+    if (!e->indexed || !e->dev) return efail(INFX_EINVAL, "sessions need an indexed engine with a GPU");
+    infx_session* S = new infx_session(); S->e = e;
+    int32_t rc = infx_stream_create(e->dev, &S->stream);
+    if (rc) { g_eerr = infx_last_error(); delete S; return rc; }
+    *out = S; return INFX_OK;
+}
+void infx_engine_session_destroy(infx_session* S) { if (!S) return; if (S->stream) infx_stream_destroy(S->stream); delete S; }
+int32_t infx_engine_session_search_batch(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
+                                         int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
+                                         uint32_t* out_counts, uint32_t* out_flags) {
+    if (!S) return efail(INFX_EINVAL, "null session");
+    return search_batch_impl(S->e, S, nq, q_arena, q_offs, max_results, depth, enable_coverage, out_keys, out_scores, out_ties, out_counts, out_flags);
+}
+int32_t infx_engine_session_last_timings(infx_session* S, double* host_ms5, float* kernel_ms3, uint64_t* alg_bytes3) {
+    if (!S) return efail(INFX_EINVAL, "null");
+    if (host_ms5) { host_ms5[0] = S->tPrep1; host_ms5[1] = S->tStage1; host_ms5[2] = S->tPrep2; host_ms5[3] = S->tStage2; host_ms5[4] = S->tPost; }
+    if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; }
+    if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; }
     return INFX_OK;
 }
 
 int32_t infx_engine_last_timings(infx_engine* e, double* host_ms5, float* kernel_ms3, uint64_t* alg_bytes3) {
     if (!e) return efail(INFX_EINVAL, "null");
-    if (host_ms5) { host_ms5[0] = e->tPrep1; host_ms5[1] = e->tStage1; host_ms5[2] = e->tPrep2; host_ms5[3] = e->tStage2; host_ms5[4] = e->tPost; }
-    if (kernel_ms3) { kernel_ms3[0] = e->msAcc; kernel_ms3[1] = e->msSel; kernel_ms3[2] = e->msCov; }
-    if (alg_bytes3) { alg_bytes3[0] = e->algBytes; alg_bytes3[1] = e->s2Candidates; alg_bytes3[2] = e->s2TextBytes; }
+    infx_session* S = e->def;
+    if (host_ms5) { host_ms5[0] = S->tPrep1; host_ms5[1] = S->tStage1; host_ms5[2] = S->tPrep2; host_ms5[3] = S->tStage2; host_ms5[4] = S->tPost; }
+    if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; }
+    if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; }
     return INFX_OK;
 }
 
@@ -360,12 +421,14 @@ int32_t infx_engine_prefix_pop(infx_engine* e, const uint16_t* p, int32_t len) {
 }
 // last batch: Stage-1 hits of query i (device order re-sorted to the reference's) and the Stage-2 records
 int32_t infx_engine_last_stage1(infx_engine* e, uint32_t qi, int64_t* keys, float* scores, int32_t cap) {
-    if (!e || qi >= e->lastPlans.size()) return -1;
+    if (!e) return -1;
+    infx_session* S = e->def;
+    if (qi >= S->lastPlans.size()) return -1;
     // recompute the device index of query qi
     uint32_t j = 0; bool found = false;
-    for (uint32_t i = 0; i < e->lastPlans.size(); i++) { const QueryPlan& P = e->lastPlans[i]; if (P.blank || P.unsupported || P.noTerms) { if (i == qi) break; continue; } if (i == qi) { found = true; break; } j++; }
+    for (uint32_t i = 0; i < S->lastPlans.size(); i++) { const QueryPlan& P = S->lastPlans[i]; if (P.blank || P.unsupported || P.noTerms) { if (i == qi) break; continue; } if (i == qi) { found = true; break; } j++; }
     if (!found) return 0;
-    uint32_t c = e->lastHitCount[j]; const infx_hit* H = e->lastHits.data() + (size_t)j * e->lastStride;
+    uint32_t c = S->lastHitCount[j]; const infx_hit* H = S->lastHits.data() + (size_t)j * S->lastStride;
     std::vector<uint32_t> o(c); for (uint32_t k = 0; k < c; k++) o[k] = k;
     std::sort(o.begin(), o.end(), [&](uint32_t x, uint32_t y) { if (H[x].score != H[y].score) return H[x].score > H[y].score; return e->ix.docKey[H[x].doc] < e->ix.docKey[H[y].doc]; });
     for (uint32_t k = 0; k < c && (int32_t)k < cap; k++) { keys[k] = e->ix.docKey[H[o[k]].doc]; scores[k] = H[o[k]].score; }
@@ -373,13 +436,14 @@ int32_t infx_engine_last_stage1(infx_engine* e, uint32_t qi, int64_t* keys, floa
 }
 int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* docs, float* base, float* scores, uint8_t* ties, int32_t* feat, int64_t cap) {
     if (!e) return -1;
-    int64_t n = (int64_t)e->lastCands.size();
+    infx_session* S = e->def;
+    int64_t n = (int64_t)S->lastCands.size();
     // map cov index -> query index
     for (int64_t i = 0; i < n && i < cap; i++) {
-        const infx_cov_cand& c = e->lastCands[i]; const infx_cov_out& o = e->lastOuts[i];
+        const infx_cov_cand& c = S->lastCands[i]; const infx_cov_out& o = S->lastOuts[i];
         if (query_of) query_of[i] = c.query; if (docs) docs[i] = c.doc; if (base) base[i] = c.base_score;
         if (scores) scores[i] = o.score; if (ties) ties[i] = o.tiebreaker;
-        if (feat) { if (e->lastFeat.size() >= (size_t)(i + 1) * INFX_NFEAT) std::memcpy(feat + (size_t)i * INFX_NFEAT, e->lastFeat.data() + (size_t)i * INFX_NFEAT, INFX_NFEAT * 4); else std::memset(feat + (size_t)i * INFX_NFEAT, 0, INFX_NFEAT * 4); }
+        if (feat) { if (S->lastFeat.size() >= (size_t)(i + 1) * INFX_NFEAT) std::memcpy(feat + (size_t)i * INFX_NFEAT, S->lastFeat.data() + (size_t)i * INFX_NFEAT, INFX_NFEAT * 4); else std::memset(feat + (size_t)i * INFX_NFEAT, 0, INFX_NFEAT * 4); }
     }
     return n;
 }
@@ -389,6 +453,6 @@ int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uin
     return (int32_t)r.size();
 }
 // raw access for bench.py (HBM-resident inputs are the engine's; these expose the flat host arrays for oracle adoption)
-int32_t infx_engine_device_handles(infx_engine* e, infx_index** idx, infx_stream** st) { if (!e) return INFX_EINVAL; if (idx) *idx = e->dev; if (st) *st = e->stream; return INFX_OK; }
+int32_t infx_engine_device_handles(infx_engine* e, infx_index** idx, infx_stream** st) { if (!e) return INFX_EINVAL; if (idx) *idx = e->dev; if (st) *st = e->def->stream; return INFX_OK; }
 
 } // extern "C"

@@ -176,6 +176,8 @@ struct HostIndex {
     // trie over all terms (label-sorted children; built from sortedTerms)
     struct TrieNode { u16 label; uint8_t pad0 = 0, pad1 = 0; int32_t term; uint32_t firstChild, nextSibling; };
     std::vector<TrieNode> trie;
+    // contiguous, label-sorted out-edges of every node (scanning a node's labels touches 1-3 cache lines, not one per child)
+    std::vector<uint32_t> edgeStart; std::vector<u16> edgeLabel; std::vector<uint32_t> edgeChild;
     // prefix DocSets
     Csr prefixAll;                  // temp
     KeyTable prefixKeys; std::vector<uint32_t> prefixPop; std::vector<int32_t> prefixSetId;   // per prefix key: population, uploaded set id or -1
@@ -388,6 +390,13 @@ inline void build_index(const DocSource& src, HostIndex& ix) {
             ix.trie[path[s.size()]].term = (int32_t)id;
             prev = s;
         }
+    }
+    {
+        size_t nn = ix.trie.size();
+        ix.edgeStart.assign(nn + 1, 0);
+        for (size_t v = 0; v < nn; v++) { uint32_t c = 0; for (uint32_t k = ix.trie[v].firstChild; k; k = ix.trie[k].nextSibling) c++; ix.edgeStart[v + 1] = ix.edgeStart[v] + c; }
+        ix.edgeLabel.resize(ix.edgeStart[nn]); ix.edgeChild.resize(ix.edgeStart[nn]);
+        for (size_t v = 0; v < nn; v++) { uint32_t p = ix.edgeStart[v]; for (uint32_t k = ix.trie[v].firstChild; k; k = ix.trie[k].nextSibling) { ix.edgeLabel[p] = ix.trie[k].label; ix.edgeChild[p] = k; p++; } }
     }
     // ---- prefix DocSets: keep the lists prefix precedence can accept, counts for the rest --------------------------------
     {

@@ -59,39 +59,54 @@ template <class T, class Cmp> inline void bcl_sort(std::vector<T>& v, Cmp cmp) {
 // path), a final node at depth j <= m+1 is reported when D[m][j] <= 1; nodes are visited in label order (pre-order).
 // A subtree is skipped when min_i(D[i][j] + max(0, j-1-i)) > 1: completing the pattern from row i needs m-i more text
 // characters but at most m+1-j remain below depth m+1, and a fresh start (row 0) deeper than column 2 costs >= 2.
+// When every live row has no error budget left, only children whose label continues an exact match are visited.
 inline int match_ld1(const HostIndex& ix, uview q, std::vector<int>& out, int cap = 1024) {
     out.clear();
-    int m = (int)q.size();
+    const int m = (int)q.size();
     if (m == 0 || m > 64 || ix.trie.empty()) return 0;
     int count = 0;
-    std::vector<std::vector<int>> col(m + 3, std::vector<int>(m + 1));
-    for (int i = 0; i <= m; i++) col[0][i] = i;
+    // column j of the DP lives at col[j*(m+1) ..]; depth <= m+1
+    std::vector<int> colv((size_t)(m + 2) * (m + 1));
+    int* col = colv.data();
+    for (int i = 0; i <= m; i++) col[i] = i;
     struct Fr { uint32_t node; int depth; };
-    std::vector<Fr> st;
-    // push children of root in reverse so that popping yields ascending labels
-    auto push_children = [&](uint32_t node, int depth) {
-        size_t base = st.size();
-        for (uint32_t c = ix.trie[node].firstChild; c; c = ix.trie[c].nextSibling) st.push_back({c, depth});
-        std::reverse(st.begin() + base, st.end());
+    Fr st[4096]; int sp = 0;                      // <= (m+1) levels x fan-out; fan-out is bounded by the alphabet in practice
+    std::vector<Fr> big;                          // overflow stack for pathological fan-outs
+    auto push = [&](uint32_t node, int depth) { if (sp < 4096) st[sp++] = {node, depth}; else big.push_back({node, depth}); };
+    auto pop = [&](Fr& f) { if (!big.empty()) { f = big.back(); big.pop_back(); return true; } if (sp == 0) return false; f = st[--sp]; return true; };
+    // children are linked in ascending label order; a stack must receive them in reverse to pop ascending
+    auto push_children = [&](uint32_t node, int depth, const u16* want, int nwant) {
+        const uint32_t eb = ix.edgeStart[node], ee = ix.edgeStart[node + 1];
+        for (uint32_t e = ee; e-- > eb;) {     // reverse: the stack then pops ascending labels
+            if (want) { const u16 lb = ix.edgeLabel[e]; bool ok = false; for (int k = 0; k < nwant; k++) if (lb == want[k]) { ok = true; break; } if (!ok) continue; }
+            push(ix.edgeChild[e], depth);
+        }
     };
-    push_children(0, 1);
-    while (!st.empty()) {
-        Fr f = st.back(); st.pop_back();
+    push_children(0, 1, nullptr, 0);              // root: row 0 has slack 1
+    Fr f;
+    while (pop(f)) {
         const auto& nd = ix.trie[f.node];
-        int j = f.depth;
-        const std::vector<int>& p = col[j - 1]; std::vector<int>& c = col[j];
+        const int j = f.depth;
+        const int* p = col + (size_t)(j - 1) * (m + 1); int* c = col + (size_t)j * (m + 1);
         c[0] = 0;
         for (int i = 1; i <= m; i++) {
             int v = p[i - 1] + (q[i - 1] == nd.label ? 0 : 1);
-            v = std::min(v, p[i] + 1); v = std::min(v, c[i - 1] + 1);
+            int u = p[i] + 1; if (u < v) v = u;
+            u = c[i - 1] + 1; if (u < v) v = u;
             c[i] = v;
         }
         if (nd.term >= 0 && c[m] <= 1) { if (count < cap) out.push_back(nd.term); count++; }
         if (j >= m + 1) continue;
-        int best = 1 << 20;
-        for (int i = 0; i <= m; i++) best = std::min(best, c[i] + std::max(0, j - 1 - i));
-        if (best > 1) continue;
-        push_children(f.node, j + 1);
+        // slack of row i: 1 - (D[i][j] + max(0, j-1-i)).  slack 1: any next label may still match; slack 0: only a diagonal
+        // MATCH keeps it alive, i.e. the next label must be q[i]; negative: dead.
+        bool any1 = false; u16 want[66]; int nwant = 0;
+        for (int i = 0; i <= m; i++) {
+            int s = 1 - (c[i] + (j - 1 - i > 0 ? j - 1 - i : 0));
+            if (s >= 1) { any1 = true; break; }
+            if (s == 0 && i < m) { bool dup = false; for (int k = 0; k < nwant; k++) if (want[k] == q[i]) { dup = true; break; } if (!dup) want[nwant++] = q[i]; }
+        }
+        if (any1) push_children(f.node, j + 1, nullptr, 0);
+        else if (nwant) push_children(f.node, j + 1, want, nwant);
     }
     return count;
 }

@@ -148,7 +148,7 @@ struct infx_stream {
     std::vector<infx_query> lastQ;            // kept between accumulate and select
     uint32_t lastNq = 0;
     float msAcc = 0, msSel = 0, msCov = 0;
-    uint64_t lastAlgBytes = 0;
+    uint64_t lastAlgBytes = 0, lastCandTotal = 0;
     bool timedAcc = false, timedSel = false, timedCov = false;
 };
 
@@ -460,7 +460,8 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     HIPCHK(hipSetDevice(ix->cfg.device));
     std::vector<SelRule> rules(nq);
     int maxDepth = 0;
-    for (uint32_t i = 0; i < nq; i++) { rules[i] = make_rule(s->lastQ[i], counts[i].c); maxDepth = std::max(maxDepth, rules[i].depth); }
+    s->lastCandTotal = 0;
+    for (uint32_t i = 0; i < nq; i++) { rules[i] = make_rule(s->lastQ[i], counts[i].c); maxDepth = std::max(maxDepth, rules[i].depth); s->lastCandTotal += rules[i].total; }
     GROW(s->dRules, s->capRules, nq * sizeof(SelRule));
     GROW(s->dHits, s->capHits, (size_t)nq * maxDepth * sizeof(infx_hit));
     GROW(s->dHitCount, s->capHitCount, (size_t)nq * 4);
@@ -524,6 +525,10 @@ int32_t infx_last_timings(infx_stream* s, float* a, float* b, float* c) {
     if (s->timedCov) hipEventElapsedTime(&s->msCov, s->evC0, s->evC1);
     if (a) *a = s->msAcc; if (b) *b = s->msSel; if (c) *c = s->msCov;
     return INFX_OK;
+}
+int32_t infx_last_candidates(infx_stream* s, uint64_t* n) {
+    if (!s || !n) return fail(INFX_EINVAL, "null argument%s");
+    *n = s->lastCandTotal; return INFX_OK;
 }
 int32_t infx_last_alg_bytes(infx_stream* s, uint64_t* bytes) {
     if (!s || !bytes) return fail(INFX_EINVAL, "null argument%s");

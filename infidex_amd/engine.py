@@ -195,11 +195,12 @@ class SearchEngine:
         return out
 
     def last_timings(self):
-        host = np.zeros(5, np.float64); kern = np.zeros(3, np.float32); alg = np.zeros(3, np.uint64)
+        host = np.zeros(5, np.float64); kern = np.zeros(3, np.float32); alg = np.zeros(5, np.uint64)
         self._check(self.L.infx_engine_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))
         return {"plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
                 "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
-                "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2])}
+                "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2]),
+                "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4])}
 
     # ---- introspection (parity tests) ----
     def index_stats(self):
@@ -257,6 +258,46 @@ class SearchEngine:
                                            _p(ties, C.c_uint8), _p(feat, C.c_int32), C.c_int64(cap))
         n = min(int(n), cap)
         return qo[:n].copy(), docs[:n].copy(), base[:n].copy(), sc[:n].copy(), ties[:n].copy(), feat[:n].copy()
+
+
+class Session:
+    """One in-flight batch (own HIP stream + scratch) on a SearchEngine; use one per host thread to overlap the host-side
+    preparation of a batch with the GPU stages of another (infidex_engine.h)."""
+
+    def __init__(self, engine: "SearchEngine"):
+        self.engine = engine
+        self.L = engine.L
+        h = C.c_void_p()
+        engine._check(self.L.infx_engine_session_create(engine.h, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.infx_engine_session_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_packed(self, arena, offs, max_results=10, depth=500, enable_coverage=True):
+        nq = len(offs) - 1
+        keys = np.full((nq, max_results), -1, np.int64); scores = np.zeros((nq, max_results), np.float32)
+        ties = np.zeros((nq, max_results), np.uint8); counts = np.zeros(nq, np.uint32); flags = np.zeros(nq, np.uint32)
+        self.engine._check(self.L.infx_engine_session_search_batch(self.h, nq, _p(arena, C.c_uint16), _p(offs, C.c_uint64), max_results, depth,
+                                                                   int(enable_coverage), _p(keys, C.c_int64), _p(scores, C.c_float),
+                                                                   _p(ties, C.c_uint8), _p(counts, C.c_uint32), _p(flags, C.c_uint32)))
+        return keys, scores, ties, counts, flags
+
+    def last_timings(self):
+        host = np.zeros(5, np.float64); kern = np.zeros(3, np.float32); alg = np.zeros(5, np.uint64)
+        self.engine._check(self.L.infx_engine_session_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))
+        return {"plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
+                "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
+                "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2]),
+                "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4])}
 
 
 def normalize(s, lower=False):
