@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--range-docs", type=int, default=0)
     ap.add_argument("--build-threads", type=int, default=0)
     ap.add_argument("--sessions", type=int, default=3, help="batches in flight (host threads, one engine session each)")
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent full-index replicas instead of document shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU-baseline sample (0 = auto, ~10-30 s)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -49,8 +50,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist_mod
+        backend = os.environ.get("INFX_DIST_BACKEND", "nccl")     # "gloo" lets two ranks share one GPU when testing the sharded flow
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
     from tools.synth import Synth, CONFIGS
     from infidex_amd import SearchEngine, Session, build as _build
@@ -83,12 +89,19 @@ def main():
 
     # ---- product: index + upload ---------------------------------------------------------------------------------------
     t0 = time.time()
-    eng = SearchEngine.create_default(device=local_rank, threads=bthreads, range_docs=args.range_docs)
+    sharded = world > 1 and not args.replicas
+    if sharded:
+        # north-star layout: the 10 M-doc index is document-sharded over the GPUs, every rank answers the SAME query stream,
+        # per-shard top-k merged by an RCCL all-gather (infidex_amd/sharded.py)
+        from infidex_amd.sharded import create_sharded_engine, ShardedSearcher, TorchComm
+        eng = create_sharded_engine(rank, world, local_rank, threads=bthreads, range_docs=args.range_docs)
+    else:
+        eng = SearchEngine.create_default(device=local_rank, threads=bthreads, range_docs=args.range_docs)
     eng.index_flat(None, arena, offs, syn.field_weights)
     t_index = time.time() - t0
 
     nsteps = args.warmup + args.steps
-    qa, qo = syn.queries(nsteps * args.batch, qseed=1000 + rank)
+    qa, qo = syn.queries(nsteps * args.batch, qseed=1000 + (0 if sharded else rank))
     batches = []
     for s in range(nsteps):
         lo, hi = s * args.batch, (s + 1) * args.batch
@@ -104,60 +117,81 @@ def main():
     # A stream of batches: `--sessions` host threads, each with its own engine session (HIP stream + scratch), pull batches from
     # a shared cursor, so the host-side preparation of one batch overlaps the GPU stages of another.  Every batch still runs the
     # complete hot path; results do not depend on the interleaving (tests/test_gpu_parity.py::test_batching_is_transparent).
-    nsess = max(1, min(args.sessions, args.steps))
-    sessions = [Session(eng) for _ in range(nsess)]
-    for s in range(args.warmup):
-        sessions[s % nsess].search_packed(batches[s][0], batches[s][1], k, 500)
-    sync()
-    tim = [None] * nsteps
-    lat = [0.0] * nsteps
-    results = [None] * nsteps
-    cursor = {"next": args.warmup}
-    lock = threading.Lock()
-    errors = []
+    if sharded:
+        searcher = ShardedSearcher(eng, TorchComm(dist))
+        for s in range(args.warmup):
+            searcher.search_packed(batches[s][0], batches[s][1], k, 500)
+        sync()
+        tim, lat, results = [], [], []
+        t_start = time.time()
+        for s in range(args.warmup, nsteps):
+            ts = time.time()
+            keys, scores, ties, counts, flags = searcher.search_packed(batches[s][0], batches[s][1], k, 500)
+            lat.append((time.time() - ts) * 1000.0)
+            tim.append(searcher.last_timings())
+            results.append((keys, counts))
+        first_keys = (results[0][0].copy(), results[0][1].copy())
+        nsess = 1
+        sessions = None
+    else:
+        nsess = max(1, min(args.sessions, args.steps))
+        sessions = [Session(eng) for _ in range(nsess)]
+        for s in range(args.warmup):
+            sessions[s % nsess].search_packed(batches[s][0], batches[s][1], k, 500)
+        sync()
+        tim = [None] * nsteps
+        lat = [0.0] * nsteps
+        results = [None] * nsteps
+        cursor = {"next": args.warmup}
+        lock = threading.Lock()
+        errors = []
 
-    def worker(sess):
-        try:
-            while True:
-                with lock:
-                    s = cursor["next"]
-                    if s >= nsteps:
-                        return
-                    cursor["next"] = s + 1
-                ts = time.time()
-                keys, scores, ties, counts, flags = sess.search_packed(batches[s][0], batches[s][1], k, 500)
-                lat[s] = (time.time() - ts) * 1000.0
-                tim[s] = sess.last_timings()
-                results[s] = (keys, counts)
-        except Exception as ex:  # noqa: BLE001
-            errors.append(ex)
+        def worker(sess):
+            try:
+                while True:
+                    with lock:
+                        s = cursor["next"]
+                        if s >= nsteps:
+                            return
+                        cursor["next"] = s + 1
+                    ts = time.time()
+                    keys, scores, ties, counts, flags = sess.search_packed(batches[s][0], batches[s][1], k, 500)
+                    lat[s] = (time.time() - ts) * 1000.0
+                    tim[s] = sess.last_timings()
+                    results[s] = (keys, counts)
+            except Exception as ex:  # noqa: BLE001
+                errors.append(ex)
 
-    t_start = time.time()
-    ths = [threading.Thread(target=worker, args=(se,)) for se in sessions]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    if errors:
-        raise errors[0]
-    tim = tim[args.warmup:]
-    lat = lat[args.warmup:]
-    first_keys = (results[args.warmup][0].copy(), results[args.warmup][1].copy())
+        t_start = time.time()
+        ths = [threading.Thread(target=worker, args=(se,)) for se in sessions]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errors:
+            raise errors[0]
+        tim = tim[args.warmup:]
+        lat = lat[args.warmup:]
+        first_keys = (results[args.warmup][0].copy(), results[args.warmup][1].copy())
     sync()
     elapsed = time.time() - t_start
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], device="cuda")
+        tt = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    total_queries = args.steps * args.batch * world     # replicas: every rank answers its own query stream
+    # sharded: all ranks cooperate on ONE stream (strong scaling of the 10 M corpus); replicas: every rank answers its own stream
+    total_queries = args.steps * args.batch * (1 if sharded else world)
     qps = total_queries / elapsed
 
     # roofline leg: the same batches once more on ONE session (no concurrent kernels), HIP events on the launch stream
     roof = []
-    for s in range(args.warmup, min(nsteps, args.warmup + 3)):
-        sessions[0].search_packed(batches[s][0], batches[s][1], k, 500)
-        roof.append(sessions[0].last_timings())
+    if sharded:
+        roof = tim
+    else:
+        for s in range(args.warmup, min(nsteps, args.warmup + 3)):
+            sessions[0].search_packed(batches[s][0], batches[s][1], k, 500)
+            roof.append(sessions[0].last_timings())
     acc_ms = float(np.mean([t["k_accumulate_ms"] for t in roof]))
     alg = float(np.mean([t["alg_bytes"] for t in roof]))
     streamed = float(np.mean([t["streamed_bytes"] for t in roof]))
@@ -165,13 +199,14 @@ def main():
     out = {
         "metric": "queries/sec, 10M-doc corpus, top-k=20 (whole hot path, index resident in HBM)",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1000.0, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1000.0, "higher_is_better": True, "scaling": ("strong" if sharded else "weak"),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE config {args.config}: {syn.cfg['docs']} docs, vocab {syn.cfg['vocab']}, {args.batch}-query batches, "
                                f"2-3 word queries {int(syn.cfg['fuzz'] * 100)}% fuzzed, depth 500, top-{k}",
                    "docs": syn.cfg["docs"], "batch": args.batch, "top_k": k, "coverage_depth": 500,
                    "sessions_in_flight": nsess,
-                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (one index per GPU, query stream split)"},
+                   "parallelism": "single GPU" if world == 1 else (f"{world} document shards, count all-reduce + RCCL all-gather of per-shard top-500 + owner-scored Stage 2" if sharded
+                                                                    else f"{world} independent replicas (one index per GPU, query stream split)")},
         "p50_batch_latency_ms": float(np.median(lat)),
         "stage_ms_per_step": {kk: float(np.mean([t[kk] for t in tim])) for kk in ("plan_ms", "stage1_ms", "prep2_ms", "stage2_ms", "post_ms",
                                                                                   "k_accumulate_ms", "k_select_ms", "k_stage2_ms")},

@@ -30,8 +30,25 @@ inline int cmp_entry(const Entry& a, const Entry& b) {    // ScoreEntry.CompareT
 
 // One in-flight batch: its own HIP stream + scratch. Several sessions on one engine let the host preparation of one batch
 // overlap the GPU stages of another (SearchEngine.Search is callable from many threads concurrently, SearchEngine.cs:258).
+struct PerQ {
+    std::vector<Entry> stage1;          // consolidated Stage-1 (score desc, key asc)
+    std::vector<int32_t> stage1Doc;     // global internal ids
+    bool runCov = false, wmAny = false, done = false;
+    uint32_t candOff = 0, candCount = 0; int covIndex = -1;
+    int32_t idx0 = -1, idx1 = -1;       // docs with docIndex 0 / 1
+};
+struct Batch {
+    uint32_t nq = 0, nd = 0; int depth = 0, maxResults = 0;
+    std::vector<infx_query> dq; std::vector<infx_term> dterms; std::vector<int32_t> extra; std::vector<uint32_t> qmap; std::vector<int> devOf;
+    std::vector<infx_counts> counts;
+    std::vector<PerQ> pq;
+    std::vector<uint32_t> localIdx;     // local Stage-2 candidates -> position in lastCands
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tPlanPar = 0;
+};
+
 struct infx_session {
     infx_engine* e = nullptr;
+    Batch* batch = nullptr;
     infx_stream* stream = nullptr;
     double tPrep1 = 0, tStage1 = 0, tPrep2 = 0, tStage2 = 0, tPost = 0;
     float msAcc = 0, msSel = 0, msCov = 0; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0;
@@ -51,6 +68,10 @@ struct infx_engine {
     bool keysAreIds = false;
     int threads = 1;
     infx_session* def = nullptr;      // default session (single-caller API)
+    // document sharding: this engine's GPU holds internal ids [shardBase, shardBase + shardN) of the corpus
+    int rank = 0, nranks = 1; int32_t shardBase = 0, shardN = 0;
+    std::vector<uint64_t> shardOff;   // sharded: per-term slice lengths prefix (T+1) of the uploaded CSR
+    uint64_t shardTermLen(int32_t t) const { return nranks > 1 ? shardOff[t + 1] - shardOff[t] : ix.terms.len((uint32_t)t); }
 };
 
 extern "C" {
@@ -72,7 +93,7 @@ int32_t infx_engine_create(const infx_engine_config* cfg, infx_engine** out) {
         int32_t rc = infx_create(&dc, &e->dev);
         if (rc) { g_eerr = infx_last_error(); delete e; return rc; }
     }
-    e->def = new infx_session(); e->def->e = e;
+    e->def = new infx_session(); e->def->e = e; e->def->batch = new Batch();
     *out = e; return INFX_OK;
 }
 
@@ -80,6 +101,7 @@ void infx_engine_destroy(infx_engine* e) {
     if (!e) return;
     infx_session* S = e->def;
     if (S && S->stream) infx_stream_destroy(S->stream);
+    if (S) delete S->batch;
     delete S;
     if (e->dev) infx_destroy(e->dev);
     delete e;
@@ -95,11 +117,49 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
     build_index(src, e->ix);
     e->keysAreIds = (keys == nullptr);
     if (keys) { e->keyToFirst.reserve((size_t)n * 2); for (int64_t d = 0; d < n; d++) e->keyToFirst.emplace(keys[d], (int32_t)d); }
+    {
+        // contiguous doc-range shard: rank r owns [r*N/W, (r+1)*N/W)
+        const int64_t N = e->ix.N, W = e->nranks, r = e->rank;
+        e->shardBase = (int32_t)(N * r / W); e->shardN = (int32_t)(N * (r + 1) / W - N * r / W);
+    }
     if (e->dev) {
         HostIndex& ix = e->ix;
-        int32_t rc = infx_upload_docs(e->dev, (uint32_t)ix.N, ix.docLen.data(), ix.avgdl, ix.docKey.data(), ix.textOff.data(), (const uint16_t*)ix.text.data());
-        if (!rc) rc = infx_upload_postings(e->dev, (uint32_t)ix.terms.K(), ix.terms.off.data(), ix.terms.doc.data(), ix.terms.w.data(), ix.df.data());
-        if (!rc) rc = infx_upload_prefix_docsets(e->dev, (uint32_t)(ix.psOff.size() - 1), ix.psOff.data(), ix.psDocs.data());
+        int32_t rc;
+        if (e->nranks == 1) {
+            rc = infx_upload_docs(e->dev, (uint32_t)ix.N, ix.docLen.data(), ix.avgdl, ix.docKey.data(), ix.textOff.data(), (const uint16_t*)ix.text.data());
+            if (!rc) rc = infx_upload_postings(e->dev, (uint32_t)ix.terms.K(), ix.terms.off.data(), ix.terms.doc.data(), ix.terms.w.data(), ix.df.data());
+            if (!rc) rc = infx_upload_prefix_docsets(e->dev, (uint32_t)(ix.psOff.size() - 1), ix.psOff.data(), ix.psDocs.data());
+        } else {
+            // global statistics (df, avgdl, N, prefix populations, word IDF) stay on the host; the GPU gets this shard's slices, rebased
+            const int32_t sb = e->shardBase, sn = e->shardN, se = sb + sn;
+            std::vector<uint64_t> to((size_t)sn + 1);
+            for (int32_t d = 0; d <= sn; d++) to[d] = ix.textOff[sb + d] - ix.textOff[sb];
+            rc = infx_upload_docs(e->dev, (uint32_t)sn, ix.docLen.data() + sb, ix.avgdl, ix.docKey.data() + sb, to.data(), (const uint16_t*)ix.text.data() + ix.textOff[sb]);
+            size_t T = ix.terms.K();
+            std::vector<uint64_t> lo(T), hi(T); e->shardOff.assign(T + 1, 0);
+            parallel_for((int64_t)T, e->threads, [&](int64_t b, int64_t en, int) {
+                for (int64_t t = b; t < en; t++) {
+                    const int32_t* p = ix.terms.doc.data(); uint64_t a = ix.terms.off[t], z = ix.terms.off[t + 1];
+                    lo[t] = std::lower_bound(p + a, p + z, sb) - p; hi[t] = std::lower_bound(p + lo[t], p + z, se) - p;
+                }
+            });
+            for (size_t t = 0; t < T; t++) e->shardOff[t + 1] = e->shardOff[t] + (hi[t] - lo[t]);
+            std::vector<int32_t> sd(e->shardOff[T]); std::vector<uint8_t> sw(e->shardOff[T]);
+            parallel_for((int64_t)T, e->threads, [&](int64_t b, int64_t en, int) {
+                for (int64_t t = b; t < en; t++) { uint64_t o = e->shardOff[t]; for (uint64_t i = lo[t]; i < hi[t]; i++, o++) { sd[o] = ix.terms.doc[i] - sb; sw[o] = ix.terms.w[i]; } }
+            });
+            if (!rc) rc = infx_upload_postings(e->dev, (uint32_t)T, e->shardOff.data(), sd.data(), sw.data(), ix.df.data());
+            size_t ns = ix.psOff.size() - 1;
+            std::vector<uint64_t> po(ns + 1, 0); std::vector<int32_t> pd;
+            for (size_t k = 0; k < ns; k++) {
+                auto a = std::lower_bound(ix.psDocs.begin() + ix.psOff[k], ix.psDocs.begin() + ix.psOff[k + 1], sb);
+                auto z = std::lower_bound(a, ix.psDocs.begin() + ix.psOff[k + 1], se);
+                for (auto it = a; it != z; ++it) pd.push_back(*it - sb);
+                po[k + 1] = pd.size();
+            }
+            if (!rc) rc = infx_upload_prefix_docsets(e->dev, (uint32_t)ns, po.data(), pd.data());
+            if (!rc) rc = infx_set_shard(e->dev, e->rank, e->nranks, sb, ix.N);
+        }
         if (!rc) rc = infx_stream_create(e->dev, &e->def->stream);
         if (rc) { g_eerr = infx_last_error(); return rc; }
     }
@@ -114,113 +174,141 @@ static int32_t key_to_id(infx_engine* e, int64_t key) {
 
 // SearchEngine.Search for a batch of queries (each = one reference Search call; results are independent of batching).
 // out_* are nq x max_results; out_flags: bit0 unsupported (short-query path), bit1 coverage stage ran, bit2 fell back to Stage 1
-static int32_t search_batch_impl(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
-                                 int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
-                                 uint32_t* out_counts, uint32_t* out_flags) {
-    if (!e || (nq && (!q_arena || !q_offs || !out_keys || !out_scores || !out_counts)) || max_results < 1) return efail(INFX_EINVAL, "bad arguments");
-    if (!e->indexed) { for (uint32_t i = 0; i < nq; i++) out_counts[i] = 0; return INFX_OK; }   // Result.MakeEmptyResult(), SearchEngine.cs:261-262
+// ------------------------------------------------------------------------------------------------------------------------
+// One batch = four phases.  Unsharded: they run back to back (search_batch_impl).  Document-sharded: the caller
+// (infidex_amd/sharded.py) interleaves the collectives — all-reduce of the class histograms after phase 1, all-gather of the
+// per-shard top-`depth` after phase 2, all-reduce of the disjoint Stage-2 records after phase 3.
+static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth) {
+    if (!e || (nq && (!q_arena || !q_offs))) return efail(INFX_EINVAL, "bad arguments");
     if (!e->dev || !S || !S->stream) return efail(INFX_EHIP, "no GPU: the scoring hot path has no CPU fallback");
     if (depth <= 0 || depth > e->ix.cfg.maxDepth) return efail(INFX_EINVAL, "CoverageDepth exceeds the engine's max_depth");
-    const HostIndex& ix = e->ix;
-    const int threads = e->threads;
+    const HostIndex& ix = e->ix; const int threads = e->threads;
+    Batch& B = *S->batch; B = Batch(); B.nq = nq; B.depth = depth;
     g_eerr.clear();
-    double t0 = now_ms();
-    // ---------------- Stage-1 planning (host, parallel over queries) ----------------
+    B.t0 = now_ms();
     std::vector<QueryPlan>& plans = S->lastPlans; plans.assign(nq, QueryPlan());
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; i++) plan_stage1(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i]);
     });
-    double tPlanPar = now_ms() - t0;
-    std::vector<infx_query> dq; std::vector<infx_term> dterms; std::vector<int32_t> extra; std::vector<uint32_t> qmap;   // device batch -> query index
-    {
-        size_t nterm = 0, nextra = 0;
-        std::vector<size_t> termBase(nq), extraBase(nq);
-        for (uint32_t i = 0; i < nq; i++) {
-            QueryPlan& P = plans[i];
-            termBase[i] = nterm; extraBase[i] = nextra;
-            if (P.blank || P.unsupported || P.noTerms) continue;
-            P.q.term_off = (uint32_t)nterm; nterm += P.terms.size();
-            for (size_t k = 0; k < P.terms.size(); k++) if (P.terms[k].term_id < 0) nextra += P.fuzzy[k]->docs.size();
-            dq.push_back(P.q); qmap.push_back(i);
-        }
-        if (nextra > 0xFFFFFFF0ull) return efail(INFX_ECAPACITY, "fuzzy unions of this batch exceed 2^32 postings; split the batch");
-        dterms.resize(nterm); extra.resize(nextra);
-        parallel_dyn(nq, threads, 8, [&](int64_t b, int64_t en, int) {
-            for (int64_t i = b; i < en; i++) {
-                QueryPlan& P = plans[i];
-                if (P.blank || P.unsupported || P.noTerms) continue;
-                size_t xo = extraBase[i];
-                for (size_t k = 0; k < P.terms.size(); k++) {
-                    infx_term t = P.terms[k];
-                    if (t.term_id < 0) { const auto& d = P.fuzzy[k]->docs; t.extra_off = (uint32_t)xo; std::memcpy(extra.data() + xo, d.data(), d.size() * 4); xo += d.size(); }
-                    dterms[termBase[i] + k] = t;
-                }
-            }
-        });
+    B.tPlanPar = now_ms() - B.t0;
+    const int32_t sb = e->shardBase, se = e->shardBase + e->shardN;
+    const bool sharded = e->nranks > 1;
+    auto shard_slice = [&](const std::vector<int32_t>& d, size_t& lo, size_t& hi) {
+        if (!sharded) { lo = 0; hi = d.size(); return; }
+        lo = std::lower_bound(d.begin(), d.end(), sb) - d.begin(); hi = std::lower_bound(d.begin(), d.end(), se) - d.begin();
+    };
+    size_t nterm = 0, nextra = 0;
+    std::vector<size_t> termBase(nq), extraBase(nq);
+    B.devOf.assign(nq, -1);
+    for (uint32_t i = 0; i < nq; i++) {
+        QueryPlan& P = plans[i];
+        termBase[i] = nterm; extraBase[i] = nextra;
+        if (P.blank || P.unsupported || P.noTerms) continue;
+        P.q.term_off = (uint32_t)nterm; nterm += P.terms.size();
+        for (size_t k = 0; k < P.terms.size(); k++) if (P.terms[k].term_id < 0) { size_t lo, hi; shard_slice(P.fuzzy[k]->docs, lo, hi); nextra += hi - lo; }
+        B.devOf[i] = (int)B.dq.size(); B.dq.push_back(P.q); B.qmap.push_back(i);
     }
-    double t1 = now_ms();
-    // ---------------- Stage 1 on the GPU ----------------
-    const uint32_t nd = (uint32_t)dq.size();
-    std::vector<infx_hit>& hits = S->lastHits; std::vector<uint32_t>& hitCount = S->lastHitCount;
-    hits.assign((size_t)nd * depth, infx_hit{0, 0.f}); hitCount.assign(nd, 0); S->lastStride = depth;
+    if (nextra > 0xFFFFFFF0ull) return efail(INFX_ECAPACITY, "fuzzy unions of this batch exceed 2^32 postings; split the batch");
+    B.dterms.resize(nterm); B.extra.resize(nextra);
+    parallel_dyn(nq, threads, 8, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; i++) {
+            QueryPlan& P = plans[i];
+            if (P.blank || P.unsupported || P.noTerms) continue;
+            size_t xo = extraBase[i];
+            for (size_t k = 0; k < P.terms.size(); k++) {
+                infx_term t = P.terms[k];
+                if (t.term_id < 0) {     // fuzzy union: global ids -> this shard's slice, rebased (its df / idf stay global)
+                    const auto& d = P.fuzzy[k]->docs; size_t lo, hi; shard_slice(d, lo, hi);
+                    t.extra_off = (uint32_t)xo; t.extra_len = (uint32_t)(hi - lo);
+                    for (size_t z = lo; z < hi; z++) B.extra[xo + (z - lo)] = d[z] - sb;
+                    xo += hi - lo;
+                }
+                B.dterms[termBase[i] + k] = t;
+            }
+        }
+    });
+    B.nd = (uint32_t)B.dq.size();
+    B.t1 = now_ms();
+    return INFX_OK;
+}
+
+static int32_t ph_accumulate(infx_engine* e, infx_session* S) {
+    Batch& B = *S->batch;
+    B.counts.assign(B.nd, infx_counts{});
     S->msAcc = S->msSel = S->msCov = 0; S->algBytes = 0;
-    if (nd) {
-        int32_t rc = infx_stage1_batch(S->stream, nd, dq.data(), (uint32_t)dterms.size(), dterms.data(), (uint32_t)extra.size(), extra.data(), hits.data(), hitCount.data());
+    if (B.nd) {
+        int32_t rc = infx_stage1_accumulate(S->stream, B.nd, B.dq.data(), (uint32_t)B.dterms.size(), B.dterms.data(), (uint32_t)B.extra.size(), B.extra.data(), B.counts.data());
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+    }
+    return INFX_OK;
+}
+
+static int32_t ph_select(infx_engine* e, infx_session* S, const infx_counts* globalCounts) {
+    Batch& B = *S->batch; const HostIndex& ix = e->ix;
+    std::vector<infx_hit>& hits = S->lastHits; std::vector<uint32_t>& hitCount = S->lastHitCount;
+    hits.assign((size_t)B.nd * B.depth, infx_hit{0, 0.f}); hitCount.assign(B.nd, 0); S->lastStride = B.depth;
+    if (B.nd) {
+        int32_t rc = infx_stage1_select(S->stream, B.nd, globalCounts, hits.data(), hitCount.data());
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
         infx_last_alg_bytes(S->stream, &S->streamedBytes);
         infx_last_candidates(S->stream, &S->s1Candidates);
-        // B_alg(q) = sum_t df_t * 5 B (4 B for fuzzy virtual terms) + card(C_q) * 4 B + depth * 12 B
+        // B_alg(q) = sum_t df_t * 5 B (4 B for fuzzy virtual terms) + card(C_q) * 4 B + depth * 12 B   (this shard's slices)
         uint64_t ab = 0;
-        for (auto& t : dterms) ab += t.term_id >= 0 ? (uint64_t)ix.terms.len((uint32_t)t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
+        for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
         uint64_t nh = 0; for (uint32_t c : hitCount) nh += c;
         S->algBytes = ab + S->s1Candidates * 4ull + nh * 12ull;
     }
-    double t2 = now_ms();
-    // ---------------- Stage-2 preparation (host) ----------------
-    struct PerQ {
-        std::vector<Entry> stage1;          // consolidated Stage-1 (score desc, key asc)
-        std::vector<int32_t> stage1Doc;
-        bool runCov = false, wmAny = false, done = false;
-        uint32_t candOff = 0, candCount = 0; int covIndex = -1;
-        int32_t idx0 = -1, idx1 = -1;       // docs with docIndex 0 / 1
-    };
-    std::vector<PerQ> pq(nq);
-    std::vector<int> devOf(nq, -1);
-    for (uint32_t j = 0; j < nd; j++) devOf[qmap[j]] = (int)j;
+    (void)ix;
+    B.t2 = now_ms();
+    return INFX_OK;
+}
+
+// allHits: W x nd x depth (global internal ids), allCounts: W x nd.  Runs the local part of Stage 2.
+static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit* allHits, const uint32_t* allCounts, int32_t max_results, int32_t enable_coverage) {
+    Batch& B = *S->batch; const HostIndex& ix = e->ix; const int threads = e->threads;
+    const uint32_t nq = B.nq, nd = B.nd; const int depth = B.depth;
+    B.maxResults = max_results;
+    std::vector<QueryPlan>& plans = S->lastPlans;
+    B.pq.assign(nq, PerQ());
     std::vector<std::vector<infx_cov_cand>> candLocal(nq);
     std::vector<infx_cov_query> covQ(nq);
     std::vector<int32_t> covErr(nq, 0);
     const bool covEnabled = ix.cfg.enableCoverage && enable_coverage;
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
-        WmResult wm; std::vector<int32_t> sortedTop, overlap, uniq;
+        WmResult wm; std::vector<int32_t> sortedTop, overlap, uniq; std::vector<infx_hit> merged;
         for (int64_t i = b; i < en; i++) {
-            QueryPlan& P = plans[i]; PerQ& S = pq[i];
-            if (P.blank || P.unsupported) { S.done = true; continue; }
-            int j = devOf[i];
+            QueryPlan& P = plans[i]; PerQ& Sq = B.pq[i];
+            if (P.blank || P.unsupported) { Sq.done = true; continue; }
+            int j = B.devOf[i];
             if (j >= 0) {
-                uint32_t c = hitCount[j];
-                S.stage1.resize(c); S.stage1Doc.resize(c);
-                // TopKHeap -> ConsolidateSegments: (score desc, key asc). Device order is (score desc, internal id asc).
-                std::vector<uint32_t> o(c); for (uint32_t k = 0; k < c; k++) o[k] = k;
-                const infx_hit* H = hits.data() + (size_t)j * depth;
-                std::sort(o.begin(), o.end(), [&](uint32_t x, uint32_t y) { if (H[x].score != H[y].score) return H[x].score > H[y].score; return ix.docKey[H[x].doc] < ix.docKey[H[y].doc]; });
-                for (uint32_t k = 0; k < c; k++) { S.stage1[k] = Entry{H[o[k]].score, ix.docKey[H[o[k]].doc], 0}; S.stage1Doc[k] = H[o[k]].doc; }
+                // global top-`depth` = best `depth` of the union of the per-shard top-`depth` lists, device order (score desc, id asc)
+                merged.clear();
+                for (int w = 0; w < W; w++) { uint32_t c = allCounts[(size_t)w * nd + j]; const infx_hit* H = allHits + ((size_t)w * nd + j) * depth; merged.insert(merged.end(), H, H + c); }
+                if (W > 1) {
+                    std::sort(merged.begin(), merged.end(), [](const infx_hit& x, const infx_hit& y) { if (x.score != y.score) return x.score > y.score; return x.doc < y.doc; });
+                    if ((int)merged.size() > depth) merged.resize(depth);
+                }
+                uint32_t c = (uint32_t)merged.size();
+                Sq.stage1.resize(c); Sq.stage1Doc.resize(c);
+                // TopKHeap -> ConsolidateSegments: (score desc, key asc)
+                std::sort(merged.begin(), merged.end(), [&](const infx_hit& x, const infx_hit& y) { if (x.score != y.score) return x.score > y.score; return ix.docKey[x.doc] < ix.docKey[y.doc]; });
+                for (uint32_t k = 0; k < c; k++) { Sq.stage1[k] = Entry{merged[k].score, ix.docKey[merged[k].doc], 0}; Sq.stage1Doc[k] = merged[k].doc; }
             }
             const ustr& st = P.searchText;
             bool isShort = !st.empty() && st.size() <= 3;
             if (isShort) for (u16 ch : st) if (is_delim(ch)) { isShort = false; break; }
-            if (isShort && (int)S.stage1.size() >= max_results) { S.done = true; continue; }     // SearchPipeline.cs:114-120
+            if (isShort && (int)Sq.stage1.size() >= max_results) { Sq.done = true; continue; }     // SearchPipeline.cs:114-120
             int shortCount = 0;
             if (isShort) { int64_t pk = ix.prefixKeys.find(st); shortCount = pk >= 0 ? (int)ix.prefixPop[pk] : 0; }
             bool skipCov = isShort && shortCount > 500;
-            if (!covEnabled || skipCov) { S.done = true; continue; }
-            S.runCov = true;
+            if (!covEnabled || skipCov) { Sq.done = true; continue; }
+            Sq.runCov = true;
             // ---- ExecuteCoverageStage preparation ----
             wm_collect(ix, st, true, wm);
-            S.wmAny = wm.any;
-            size_t ntop = std::min<size_t>(S.stage1.size(), (size_t)depth);
-            sortedTop.assign(S.stage1Doc.begin(), S.stage1Doc.begin() + ntop);
+            Sq.wmAny = wm.any;
+            size_t ntop = std::min<size_t>(Sq.stage1.size(), (size_t)depth);
+            sortedTop.assign(Sq.stage1Doc.begin(), Sq.stage1Doc.begin() + ntop);
             std::sort(sortedTop.begin(), sortedTop.end());
             overlap.clear();
             if (wm.any) for (int32_t d : sortedTop) if (wm_contains(wm, d)) overlap.push_back(d);   // ascending
@@ -229,59 +317,80 @@ static int32_t search_batch_impl(infx_engine* e, infx_session* S, uint32_t nq, c
             wm_first_unique(wm, sortedTop, need, uniq);
             // docIndex 0/1 = first two keys in insertion order: Stage-1 docs, then WordMatcher-only ids ascending
             int32_t first2[2] = {-1, -1}; int nf = 0;
-            for (size_t k = 0; k < ntop && nf < 2; k++) first2[nf++] = S.stage1Doc[k];
+            for (size_t k = 0; k < ntop && nf < 2; k++) first2[nf++] = Sq.stage1Doc[k];
             for (size_t k = 0; k < uniq.size() && nf < 2; k++) first2[nf++] = uniq[k];
-            S.idx0 = first2[0]; S.idx1 = first2[1];
+            Sq.idx0 = first2[0]; Sq.idx1 = first2[1];
             covErr[i] = prepare_cov_query(ix, st, covQ[i]);
             if (covErr[i]) continue;
             auto& CL = candLocal[i];
             auto push = [&](int32_t doc, float base) { infx_cov_cand c{}; c.query = 0; c.doc = doc; c.base_score = base; c.want_lcs = (doc == first2[0] || doc == first2[1]) ? 1 : 0; CL.push_back(c); };
             for (int32_t d : overlap) push(d, 0.f);
             for (size_t k = 0; k < uniq.size() && k < wmLimit; k++) push(uniq[k], 0.f);
-            float maxT = ntop ? S.stage1[0].score : 1.f;
-            for (size_t k = 0; k < ntop; k++) push(S.stage1Doc[k], maxT > 0 ? S.stage1[k].score / maxT : 0.f);
+            float maxT = ntop ? Sq.stage1[0].score : 1.f;
+            for (size_t k = 0; k < ntop; k++) push(Sq.stage1Doc[k], maxT > 0 ? Sq.stage1[k].score / maxT : 0.f);
         }
     });
     for (uint32_t i = 0; i < nq; i++) if (covErr[i]) return efail(covErr[i], "query exceeds the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length)");
     std::vector<infx_cov_query> covBatch; std::vector<infx_cov_cand>& cands = S->lastCands; cands.clear();
     for (uint32_t i = 0; i < nq; i++) {
-        PerQ& S = pq[i];
-        if (!S.runCov) continue;
-        S.covIndex = (int)covBatch.size(); covBatch.push_back(covQ[i]);
-        S.candOff = (uint32_t)cands.size(); S.candCount = (uint32_t)candLocal[i].size();
-        for (auto c : candLocal[i]) { c.query = (uint32_t)S.covIndex; cands.push_back(c); }
+        PerQ& Sq = B.pq[i];
+        if (!Sq.runCov) continue;
+        Sq.covIndex = (int)covBatch.size(); covBatch.push_back(covQ[i]);
+        Sq.candOff = (uint32_t)cands.size(); Sq.candCount = (uint32_t)candLocal[i].size();
+        for (auto c : candLocal[i]) { c.query = (uint32_t)Sq.covIndex; cands.push_back(c); }
     }
-    double t3 = now_ms();
-    // ---------------- Stage 2 on the GPU ----------------
+    B.t3 = now_ms();
+    // ---------------- Stage 2 on the GPU: the candidates whose text this shard holds ----------------
     std::vector<infx_cov_out>& outs = S->lastOuts; outs.assign(cands.size(), infx_cov_out{});
-    S->s2Candidates = cands.size(); S->s2TextBytes = 0;
-    for (auto& c : cands) S->s2TextBytes += 2 * (ix.textOff[c.doc + 1] - ix.textOff[c.doc]);
-    if (e->cfg.want_features) S->lastFeat.assign(cands.size() * INFX_NFEAT, 0);
-    if (!cands.empty()) {
-        int32_t rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)cands.size(), cands.data(), outs.data(), e->cfg.want_features ? S->lastFeat.data() : nullptr);
+    const int32_t sb = e->shardBase, se = e->shardBase + e->shardN;
+    std::vector<infx_cov_cand> local; B.localIdx.clear();
+    S->s2Candidates = 0; S->s2TextBytes = 0;
+    for (size_t i = 0; i < cands.size(); i++) {
+        const infx_cov_cand& c = cands[i];
+        if (c.doc < sb || c.doc >= se) continue;
+        infx_cov_cand l = c; l.doc = c.doc - sb; local.push_back(l); B.localIdx.push_back((uint32_t)i);
+        S->s2TextBytes += 2 * (ix.textOff[c.doc + 1] - ix.textOff[c.doc]);
+    }
+    S->s2Candidates = local.size();
+    std::vector<infx_cov_out> lout(local.size());
+    std::vector<int32_t> lfeat;
+    if (e->cfg.want_features) { S->lastFeat.assign(cands.size() * INFX_NFEAT, 0); lfeat.assign(local.size() * INFX_NFEAT, 0); }
+    if (!local.empty()) {
+        int32_t rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)local.size(), local.data(), lout.data(), e->cfg.want_features ? lfeat.data() : nullptr);
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(S->stream, nullptr, nullptr, &S->msCov);
-        for (auto& o : outs) if (o.status) return efail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)");
+        for (auto& o : lout) if (o.status) return efail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)");
+        for (size_t i = 0; i < local.size(); i++) {
+            outs[B.localIdx[i]] = lout[i];
+            if (e->cfg.want_features) std::memcpy(S->lastFeat.data() + (size_t)B.localIdx[i] * INFX_NFEAT, lfeat.data() + i * INFX_NFEAT, INFX_NFEAT * 4);
+        }
     }
-    double t4 = now_ms();
-    // ---------------- final ordering / truncation (host) ----------------
+    B.t4 = now_ms();
+    return INFX_OK;
+}
+
+static int32_t ph_finalize(infx_engine* e, infx_session* S, const infx_cov_out* outs, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
+                           uint32_t* out_counts, uint32_t* out_flags) {
+    Batch& B = *S->batch; const HostIndex& ix = e->ix; const int threads = e->threads;
+    const uint32_t nq = B.nq; const int depth = B.depth, max_results = B.maxResults;
+    std::vector<QueryPlan>& plans = S->lastPlans; std::vector<infx_cov_cand>& cands = S->lastCands;
     parallel_dyn(nq, threads, 8, [&](int64_t b, int64_t en, int) {
         std::vector<Entry> fin, cons;
         for (int64_t i = b; i < en; i++) {
-            PerQ& S = pq[i]; const QueryPlan& P = plans[i];
-            uint32_t flags = 0; const std::vector<Entry>* res = &S.stage1;
+            PerQ& Sq = B.pq[i]; const QueryPlan& P = plans[i];
+            uint32_t flags = 0; const std::vector<Entry>* res = &Sq.stage1;
             if (P.unsupported) flags |= 1;
-            if (S.runCov) {
+            if (Sq.runCov) {
                 flags |= 2;
                 int maxWordHits = 0; uint8_t hits01[2] = {0, 0}, lcs01[2] = {0, 0};
                 fin.clear();
-                for (uint32_t k = 0; k < S.candCount; k++) {
-                    const infx_cov_cand& c = cands[S.candOff + k]; const infx_cov_out& o = outs[S.candOff + k];
+                for (uint32_t k = 0; k < Sq.candCount; k++) {
+                    const infx_cov_cand& c = cands[Sq.candOff + k]; const infx_cov_out& o = outs[Sq.candOff + k];
                     maxWordHits = std::max(maxWordHits, o.word_hits_full);
-                    for (int z = 0; z < 2; z++) { int32_t dz = z == 0 ? S.idx0 : S.idx1; if (dz >= 0 && c.doc == dz) { if (hits01[z] == 0) hits01[z] = o.word_hits; if (lcs01[z] == 0) lcs01[z] = o.lcs; } }
+                    for (int z = 0; z < 2; z++) { int32_t dz = z == 0 ? Sq.idx0 : Sq.idx1; if (dz >= 0 && c.doc == dz) { if (hits01[z] == 0) hits01[z] = o.word_hits; if (lcs01[z] == 0) lcs01[z] = o.lcs; } }
                     fin.push_back(Entry{o.score, ix.docKey[c.doc], o.tiebreaker});
                 }
-                if (maxWordHits == 0 && !S.wmAny) { cons.clear(); }
+                if (maxWordHits == 0 && !Sq.wmAny) { cons.clear(); }
                 else {
                     // TopKHeap(depth): best `depth` by the total order, then ConsolidateSegments (best per key, descending)
                     std::sort(fin.begin(), fin.end(), [](const Entry& a, const Entry& c) { return cmp_entry(a, c) > 0; });
@@ -291,17 +400,17 @@ static int32_t search_batch_impl(infx_engine* e, infx_session* S, uint32_t nq, c
                     for (auto& x : fin) if (seen.emplace(x.key, 1).second) cons.push_back(x);
                     int truncIdx = -1;
                     int minHits = std::max(1, maxWordHits - 0);
-                    int64_t k0 = S.idx0 >= 0 ? ix.docKey[S.idx0] : INT64_MIN, k1 = S.idx1 >= 0 ? ix.docKey[S.idx1] : INT64_MIN;
+                    int64_t k0 = Sq.idx0 >= 0 ? ix.docKey[Sq.idx0] : INT64_MIN, k1 = Sq.idx1 >= 0 ? ix.docKey[Sq.idx1] : INT64_MIN;
                     for (int r = (int)cons.size() - 1; r >= 0; r--) {
                         uint8_t wh = 0, lc = 0;
-                        if (S.idx0 >= 0 && cons[r].key == k0) { wh = hits01[0]; lc = lcs01[0]; }
-                        else if (S.idx1 >= 0 && cons[r].key == k1) { wh = hits01[1]; lc = lcs01[1]; }
+                        if (Sq.idx0 >= 0 && cons[r].key == k0) { wh = hits01[0]; lc = lcs01[0]; }
+                        else if (Sq.idx1 >= 0 && cons[r].key == k1) { wh = hits01[1]; lc = lcs01[1]; }
                         if (wh >= minHits || lc > 0 || cons[r].score >= 254.f) { truncIdx = r; break; }
                     }
                     int resultCount = truncIdx == -1 ? max_results : std::min(std::max(0, truncIdx) + 1, max_results);
                     if ((int)cons.size() > resultCount) cons.resize(resultCount);
                 }
-                if (cons.empty() && !S.stage1.empty()) { flags |= 4; res = &S.stage1; } else res = &cons;
+                if (cons.empty() && !Sq.stage1.empty()) { flags |= 4; res = &Sq.stage1; } else res = &cons;
             }
             uint32_t cnt = (uint32_t)std::min<size_t>(res->size(), (size_t)max_results);
             out_counts[i] = cnt;
@@ -319,11 +428,24 @@ static int32_t search_batch_impl(infx_engine* e, infx_session* S, uint32_t nq, c
             for (auto& t : P.terms) dfsum[P.q.mode] += t.term_id >= 0 ? (unsigned long long)ix.terms.len((uint32_t)t.term_id) : t.extra_len; }
         fprintf(stderr, "[infx] modes: prefix=%d disj=%d and=%d | postings per mode: %llu %llu %llu | maxT=%zu\n", nm[1], nm[2], nm[3], dfsum[1], dfsum[2], dfsum[3], maxT);
         fprintf(stderr, "[infx] nq=%u dev=%u terms=%zu extra=%zu cands=%zu | plan %.1f (build %.1f) s1 %.1f prep2 %.1f s2 %.1f post %.1f ms | fuzzy calls=%lld %.1f ms-cpu (ld1 %.1f) docs=%lld\n",
-                nq, nd, dterms.size(), extra.size(), cands.size(), t1 - t0, tPlanPar, t2 - t1, t3 - t2, t4 - t3, t5 - t4,
+                nq, B.nd, B.dterms.size(), B.extra.size(), cands.size(), B.t1 - B.t0, B.tPlanPar, B.t2 - B.t1, B.t3 - B.t2, B.t4 - B.t3, t5 - B.t4,
                 (long long)e->fuzzy.fuzzyCalls.exchange(0), e->fuzzy.fuzzyNs.exchange(0) / 1e6, e->fuzzy.ld1Ns.exchange(0) / 1e6, (long long)e->fuzzy.fuzzyDocs.exchange(0));
     }
-    S->tPrep1 = t1 - t0; S->tStage1 = t2 - t1; S->tPrep2 = t3 - t2; S->tStage2 = t4 - t3; S->tPost = t5 - t4;
+    S->tPrep1 = B.t1 - B.t0; S->tStage1 = B.t2 - B.t1; S->tPrep2 = B.t3 - B.t2; S->tStage2 = B.t4 - B.t3; S->tPost = t5 - B.t4;
     return INFX_OK;
+}
+
+static int32_t search_batch_impl(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
+                                 int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
+                                 uint32_t* out_counts, uint32_t* out_flags) {
+    if (!e || (nq && (!q_arena || !q_offs || !out_keys || !out_scores || !out_counts)) || max_results < 1) return efail(INFX_EINVAL, "bad arguments");
+    if (!e->indexed) { for (uint32_t i = 0; i < nq; i++) out_counts[i] = 0; return INFX_OK; }   // Result.MakeEmptyResult(), SearchEngine.cs:261-262
+    if (e->nranks > 1) return efail(INFX_EINVAL, "sharded engine: drive the phase API (infx_session_phase1..4) with the collectives in between");
+    int32_t rc = ph_plan(e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
+    rc = ph_accumulate(e, S); if (rc) return rc;
+    rc = ph_select(e, S, S->batch->counts.data()); if (rc) return rc;
+    rc = ph_stage2(e, S, 1, S->lastHits.data(), S->lastHitCount.data(), max_results, enable_coverage); if (rc) return rc;
+    return ph_finalize(e, S, S->lastOuts.data(), out_keys, out_scores, out_ties, out_counts, out_flags);
 }
 
 int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
@@ -335,18 +457,60 @@ int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_
 int32_t infx_engine_session_create(infx_engine* e, infx_session** out) {
     if (!e || !out) return efail(INFX_EINVAL, "null");
     if (!e->indexed || !e->dev) return efail(INFX_EINVAL, "sessions need an indexed engine with a GPU");
-    infx_session* S = new infx_session(); S->e = e;
+    infx_session* S = new infx_session(); S->e = e; S->batch = new Batch();
     int32_t rc = infx_stream_create(e->dev, &S->stream);
-    if (rc) { g_eerr = infx_last_error(); delete S; return rc; }
+    if (rc) { g_eerr = infx_last_error(); delete S->batch; delete S; return rc; }
     *out = S; return INFX_OK;
 }
-void infx_engine_session_destroy(infx_session* S) { if (!S) return; if (S->stream) infx_stream_destroy(S->stream); delete S; }
+void infx_engine_session_destroy(infx_session* S) { if (!S) return; if (S->stream) infx_stream_destroy(S->stream); delete S->batch; delete S; }
 int32_t infx_engine_session_search_batch(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
                                          int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                          uint32_t* out_counts, uint32_t* out_flags) {
     if (!S) return efail(INFX_EINVAL, "null session");
     return search_batch_impl(S->e, S, nq, q_arena, q_offs, max_results, depth, enable_coverage, out_keys, out_scores, out_ties, out_counts, out_flags);
 }
+// ---- sharded operation: phases with the collectives in between (infidex_amd/sharded.py) ----
+int32_t infx_engine_set_shard(infx_engine* e, int32_t rank, int32_t nranks) {
+    if (!e || nranks < 1 || rank < 0 || rank >= nranks) return efail(INFX_EINVAL, "bad shard arguments");
+    if (e->indexed) return efail(INFX_EINVAL, "set the shard before IndexDocuments");
+    e->rank = rank; e->nranks = nranks; return INFX_OK;
+}
+int32_t infx_engine_shard_info(infx_engine* e, int32_t* base, int32_t* n) { if (!e) return INFX_EINVAL; if (base) *base = e->shardBase; if (n) *n = e->shardN; return INFX_OK; }
+int32_t infx_session_phase1(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, uint32_t* ndev) {
+    if (!S) return efail(INFX_EINVAL, "null session");
+    int32_t rc = ph_plan(S->e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
+    rc = ph_accumulate(S->e, S); if (rc) return rc;
+    if (ndev) *ndev = S->batch->nd;
+    return INFX_OK;
+}
+int32_t infx_session_counts(infx_session* S, uint32_t* counts) {   // nd x INFX_NCLASS, this shard
+    if (!S || !counts) return efail(INFX_EINVAL, "null");
+    std::memcpy(counts, S->batch->counts.data(), S->batch->counts.size() * sizeof(infx_counts)); return INFX_OK;
+}
+int32_t infx_session_phase2(infx_session* S, const uint32_t* global_counts, infx_hit* hits, uint32_t* hitcounts) {
+    if (!S || !global_counts) return efail(INFX_EINVAL, "null");
+    int32_t rc = ph_select(S->e, S, (const infx_counts*)global_counts); if (rc) return rc;
+    if (hits) std::memcpy(hits, S->lastHits.data(), S->lastHits.size() * sizeof(infx_hit));
+    if (hitcounts) std::memcpy(hitcounts, S->lastHitCount.data(), S->lastHitCount.size() * 4);
+    return INFX_OK;
+}
+int32_t infx_session_phase3(infx_session* S, int32_t W, const infx_hit* all_hits, const uint32_t* all_counts, int32_t max_results, int32_t enable_coverage, uint64_t* ncand) {
+    if (!S || W < 1 || max_results < 1) return efail(INFX_EINVAL, "bad arguments");
+    int32_t rc = ph_stage2(S->e, S, W, all_hits, all_counts, max_results, enable_coverage); if (rc) return rc;
+    if (ncand) *ncand = S->lastCands.size();
+    return INFX_OK;
+}
+int32_t infx_session_outs(infx_session* S, int32_t* outs3) {   // ncand x 3 int32 words; zeros for candidates another shard owns
+    if (!S || !outs3) return efail(INFX_EINVAL, "null");
+    static_assert(sizeof(infx_cov_out) == 12, "infx_cov_out is exchanged as 3 int32 words");
+    std::memcpy(outs3, S->lastOuts.data(), S->lastOuts.size() * sizeof(infx_cov_out)); return INFX_OK;
+}
+int32_t infx_session_phase4(infx_session* S, const int32_t* merged_outs3, int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags) {
+    if (!S || !merged_outs3 || !out_keys || !out_scores || !out_counts) return efail(INFX_EINVAL, "null");
+    return ph_finalize(S->e, S, (const infx_cov_out*)merged_outs3, out_keys, out_scores, out_ties, out_counts, out_flags);
+}
+int32_t infx_engine_default_session(infx_engine* e, infx_session** out) { if (!e || !out) return INFX_EINVAL; *out = e->def; return INFX_OK; }
+
 int32_t infx_engine_session_last_timings(infx_session* S, double* host_ms5, float* kernel_ms3, uint64_t* alg_bytes3) {
     if (!S) return efail(INFX_EINVAL, "null");
     if (host_ms5) { host_ms5[0] = S->tPrep1; host_ms5[1] = S->tStage1; host_ms5[2] = S->tPrep2; host_ms5[3] = S->tStage2; host_ms5[4] = S->tPost; }

@@ -1,0 +1,145 @@
+"""Document-sharded search across the GPUs of one node.
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gloo" for CPU tests of the plumbing).
+Every rank indexes the whole corpus on the host (global df / avgdl / N, exactly like the reference's single index), uploads
+its contiguous doc range, and runs each batch as four phases of the C++ engine with three small collectives in between:
+
+    phase1  plan + k_accumulate                      -> all-reduce(sum)  class histograms   (Exchange 1: tier decisions, quirk Q11)
+    phase2  k_select with the GLOBAL counts          -> all-gather       per-shard top-`depth` (Exchange 2: the north-star collective)
+    phase3  merge, Stage-2 prep, k_stage2 on OWNED candidates -> all-reduce(sum) of the disjoint 12-byte records
+    phase4  final ordering / truncation (identical on every rank)
+"""
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+
+from .engine import SearchEngine, Session, _p, INFX_NFEAT  # noqa: F401
+
+INFX_NCLASS = 136
+
+
+class TorchComm:
+    """numpy <-> torch.distributed adaptor. With backend nccl the tensors live on this rank's GPU (RCCL), with gloo on the CPU."""
+
+    def __init__(self, dist, device=None):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.device = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
+                                                         if dist.get_backend() == "nccl" else torch.device("cpu"))
+
+    def allreduce_sum_i32(self, a: np.ndarray) -> np.ndarray:
+        t = self.torch.from_numpy(np.ascontiguousarray(a.view(np.int32))).clone().to(self.device)   # never alias the caller's array
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy().view(a.dtype).reshape(a.shape)
+
+    def allgather(self, a: np.ndarray) -> np.ndarray:
+        """Returns an array of shape (world, *a.shape); a must have the same shape on every rank."""
+        t = self.torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(self.device)
+        out = self.torch.empty(self.world * t.numel(), dtype=t.dtype, device=self.device)   # flat: accepted by both RCCL and gloo
+        self.dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy().view(a.dtype).reshape((self.world,) + a.shape)
+
+    def max_i64(self, v: int) -> int:
+        t = self.torch.tensor([v], dtype=self.torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
+
+
+def create_sharded_engine(rank: int, world: int, device: int, **kw) -> SearchEngine:
+    eng = SearchEngine.create_default(device=device, **kw)
+    eng._check(eng.L.infx_engine_set_shard(eng.h, rank, world))
+    return eng
+
+
+class ShardSession:
+    """Phase-level access to one engine session (used by ShardedSearcher and by the single-process shard simulation)."""
+
+    def __init__(self, engine: SearchEngine):
+        self.e = engine
+        self.L = engine.L
+        self.s = Session(engine)
+
+    def phase1(self, arena, offs, depth):
+        nd = C.c_uint32(0)
+        self.nq = len(offs) - 1
+        self.depth = depth
+        self.e._check(self.L.infx_session_phase1(self.s.h, self.nq, _p(arena, C.c_uint16), _p(offs, C.c_uint64), depth, C.byref(nd)))
+        self.nd = nd.value
+        counts = np.zeros((max(self.nd, 1), INFX_NCLASS), np.uint32)
+        if self.nd:
+            self.e._check(self.L.infx_session_counts(self.s.h, _p(counts, C.c_uint32)))
+        return counts[:self.nd]
+
+    def phase2(self, global_counts):
+        hits = np.zeros((max(self.nd, 1), self.depth, 2), np.int32)     # (doc:int32, score bits:int32)
+        hc = np.zeros(max(self.nd, 1), np.uint32)
+        gc = np.ascontiguousarray(global_counts, np.uint32)
+        if gc.size == 0:
+            gc = np.zeros((1, INFX_NCLASS), np.uint32)
+        self.e._check(self.L.infx_session_phase2(self.s.h, _p(gc, C.c_uint32), hits.ctypes.data_as(C.c_void_p), _p(hc, C.c_uint32)))
+        return hits[:self.nd], hc[:self.nd]
+
+    def phase3(self, all_hits, all_hc, max_results, enable_coverage=True):
+        W = all_hits.shape[0]
+        ah = np.ascontiguousarray(all_hits, np.int32)
+        ac = np.ascontiguousarray(all_hc, np.uint32)
+        if ah.size == 0:
+            ah = np.zeros((W, 1, self.depth, 2), np.int32); ac = np.zeros((W, 1), np.uint32)
+        ncand = C.c_uint64(0)
+        self.max_results = max_results
+        self.e._check(self.L.infx_session_phase3(self.s.h, W, ah.ctypes.data_as(C.c_void_p), _p(ac, C.c_uint32), max_results, int(enable_coverage), C.byref(ncand)))
+        self.ncand = ncand.value
+        outs = np.zeros((max(self.ncand, 1), 3), np.int32)
+        if self.ncand:
+            self.e._check(self.L.infx_session_outs(self.s.h, _p(outs, C.c_int32)))
+        return outs[:self.ncand]
+
+    def phase4(self, merged_outs):
+        nq, mr = self.nq, self.max_results
+        keys = np.full((nq, mr), -1, np.int64); scores = np.zeros((nq, mr), np.float32)
+        ties = np.zeros((nq, mr), np.uint8); counts = np.zeros(nq, np.uint32); flags = np.zeros(nq, np.uint32)
+        mo = np.ascontiguousarray(merged_outs, np.int32)
+        if mo.size == 0:
+            mo = np.zeros((1, 3), np.int32)
+        self.e._check(self.L.infx_session_phase4(self.s.h, _p(mo, C.c_int32), _p(keys, C.c_int64), _p(scores, C.c_float), _p(ties, C.c_uint8),
+                                                 _p(counts, C.c_uint32), _p(flags, C.c_uint32)))
+        return keys, scores, ties, counts, flags
+
+
+class ShardedSearcher:
+    """One rank of a document-sharded deployment. All ranks must call search_packed with the same batch."""
+
+    def __init__(self, engine: SearchEngine, comm: TorchComm):
+        self.sess = ShardSession(engine)
+        self.comm = comm
+
+    def search_packed(self, arena, offs, max_results=10, depth=500, enable_coverage=True):
+        c = self.comm
+        counts = self.sess.phase1(arena, offs, depth)
+        gcounts = c.allreduce_sum_i32(counts) if counts.size else counts                       # Exchange 1
+        hits, hc = self.sess.phase2(gcounts)
+        all_hits = c.allgather(hits) if hits.size else hits.reshape((c.world,) + hits.shape)      # Exchange 2 (RCCL all-gather of top-k)
+        all_hc = c.allgather(hc) if hc.size else hc.reshape((c.world,) + hc.shape)
+        outs = self.sess.phase3(all_hits, all_hc, max_results, enable_coverage)
+        merged = c.allreduce_sum_i32(outs) if outs.size else outs                              # disjoint Stage-2 records
+        return self.sess.phase4(merged)
+
+    def last_timings(self):
+        return self.sess.s.last_timings()
+
+
+def simulate_shards(sessions: Sequence[ShardSession], arena, offs, max_results=10, depth=500, enable_coverage=True):
+    """Single-process lock-step simulation of W shards (e.g. W engines on ONE GPU): same phases, numpy instead of RCCL.
+    Used by the GPU parity test to check that the sharded path reproduces the unsharded results."""
+    counts = [s.phase1(arena, offs, depth) for s in sessions]
+    g = np.sum(np.stack(counts).astype(np.uint64), axis=0).astype(np.uint32)
+    ph2 = [s.phase2(g) for s in sessions]
+    all_hits = np.stack([h for h, _ in ph2]); all_hc = np.stack([c for _, c in ph2])
+    outs = [s.phase3(all_hits, all_hc, max_results, enable_coverage) for s in sessions]
+    merged = np.sum(np.stack(outs).astype(np.int64), axis=0).astype(np.int32) if outs[0].size else outs[0]
+    res = [s.phase4(merged) for s in sessions]
+    return res

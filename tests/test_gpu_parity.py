@@ -169,3 +169,28 @@ def test_batching_is_transparent(synth_pair):
     for x, y in zip(a[:16], b):
         assert [r.document_id for r in x.records] == [r.document_id for r in y.records]
         assert [r.score for r in x.records] == [r.score for r in y.records]   # deterministic, batch-independent
+
+
+def test_sharded_equals_unsharded():
+    """Two doc-range shards (simulated on one GPU, numpy in place of RCCL) reproduce the single-index results exactly:
+    global statistics + count all-reduce + top-k all-gather + owner-scored Stage 2."""
+    from infidex_amd.sharded import create_sharded_engine, ShardSession, simulate_shards
+    from infidex_amd.engine import pack_texts
+    s = Synth(2, docs=30000)
+    arena, offs = s.docs()
+    ref = SearchEngine.create_default(device=0); ref.index_flat(None, arena, offs, s.field_weights)
+    W = 3
+    engs = [create_sharded_engine(r, W, 0) for r in range(W)]
+    for e in engs:
+        e.index_flat(None, arena, offs, s.field_weights)
+    sess = [ShardSession(e) for e in engs]
+    qa, qo = s.queries(200, qseed=21, fuzz=0.3)
+    qs = Synth.texts(qa, qo) + ["qu", "zzzzqq", "the"]
+    a2, o2 = pack_texts(qs)
+    rk, rs, rt, rc, rf = ref.search_packed(a2, o2, 10)
+    res = simulate_shards(sess, a2, o2, 10)
+    for (k, sc, t, c, f) in res:
+        assert np.array_equal(c, rc)
+        assert np.array_equal(k, rk)
+        assert np.array_equal(sc, rs)      # bit-identical scores: same kernels, same arithmetic, only the doc ranges differ
+        assert np.array_equal(t, rt)
