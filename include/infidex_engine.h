@@ -60,7 +60,8 @@ int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, floa
 
 /* Document-sharded operation: every rank indexes the whole corpus on the host (global df / avgdl / N), uploads
  * its contiguous doc range, and a batch runs as four phases with the collectives in between:
- *   phase1 (plan + k_accumulate)  -> all-reduce(sum) of infx_session_counts (ndev x INFX_NCLASS)          [Exchange 1]
+ *   phase0 (text prep, LD1 member lists, k_union_count) -> all-reduce(sum) of infx_session_union_counts    [Exchange 1b: fuzzy df]
+ *   phase1 (idf/roles + k_accumulate)  -> all-reduce(sum) of infx_session_counts (ndev x INFX_NCLASS)     [Exchange 1]
  *   phase2 (k_select, global counts) -> all-gather of hits (ndev x depth) and hit counts                  [Exchange 2, RCCL over xGMI]
  *   phase3 (merge to the global top-depth, Stage-2 prep, k_stage2 on the OWNED candidates)
  *          -> all-reduce(sum) of infx_session_outs (ncand x 3 int32; every candidate is scored by exactly one shard)
@@ -68,7 +69,9 @@ int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, floa
 int32_t infx_engine_set_shard(infx_engine* e, int32_t rank, int32_t nranks);      /* before infx_engine_index_documents */
 int32_t infx_engine_shard_info(infx_engine* e, int32_t* doc_base, int32_t* num_docs);
 int32_t infx_engine_default_session(infx_engine* e, infx_session** out);
-int32_t infx_session_phase1(infx_session* s, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, uint32_t* ndev);
+int32_t infx_session_phase0(infx_session* s, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, uint32_t* nunions);
+int32_t infx_session_union_counts(infx_session* s, uint32_t* counts);
+int32_t infx_session_phase1(infx_session* s, const uint32_t* global_union_counts, uint32_t* ndev);
 int32_t infx_session_counts(infx_session* s, uint32_t* counts);
 int32_t infx_session_phase2(infx_session* s, const uint32_t* global_counts, infx_hit* hits, uint32_t* hitcounts);
 int32_t infx_session_phase3(infx_session* s, int32_t nranks, const infx_hit* all_hits, const uint32_t* all_hitcounts, int32_t max_results,

@@ -84,7 +84,9 @@ typedef struct infx_term {
     float    max_score;    /* VectorModel.cs:525-531 */
     uint8_t  role;         /* INFX_ROLE_* bits: membership in the candidate tiers */
     uint8_t  rank;         /* disjunctive: position in the IDF-descending order among eligible terms (TieredCandidateSelector.cs:253) */
-    uint16_t reserved;
+    uint16_t reserved;     /* virtual term only: 0 = extra_docs[extra_off..+len) are the union's doc ids (shard-local, ascending);
+                              1 = they are the MEMBER TERM IDS (<= LD1 matches, VectorModel.cs:660-683): the union is formed on the
+                              device (one posting stream per member, each document counted once), its df comes from infx_union_counts */
 } infx_term;
 
 #define INFX_ROLE_AND      1   /* AND mode: member of terms[0..n-2] (everything but the lowest-IDF term) */
@@ -125,6 +127,10 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
 /* Convenience for the unsharded case: accumulate + select. == Bm25Scorer.Search for a batch of queries. */
 int32_t infx_stage1_batch(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
                           uint32_t extra_n, const int32_t* extra_docs, infx_hit* out, uint32_t* out_count);
+
+/* df of fuzzy virtual terms on this shard: counts_out[v] = |union of the doc sets of members[member_offs[v] .. member_offs[v+1])|
+ * (RoaringBitmap.Create(allFuzzyDocs).Cardinality, VectorModel.cs:722-729). Sum over shards before computing idf (Exchange 1b). */
+int32_t infx_union_counts(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out);
 
 /* ---- Stage 2 ------------------------------------------------------------------------------------------------- */
 /* CoverageQueryContext (Coverage/CoverageEngine.cs:9-43) of one query, prepared on the host (PrepareQuery :61-126). */

@@ -43,6 +43,7 @@ struct Batch {
     std::vector<infx_counts> counts;
     std::vector<PerQ> pq;
     std::vector<uint32_t> localIdx;     // local Stage-2 candidates -> position in lastCands
+    std::vector<std::shared_ptr<FuzzyUnion>> pending; std::vector<uint32_t> pendingCounts;   // unions whose df this batch counts
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tPlanPar = 0;
 };
 
@@ -188,8 +189,29 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
     B.t0 = now_ms();
     std::vector<QueryPlan>& plans = S->lastPlans; plans.assign(nq, QueryPlan());
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
-        for (int64_t i = b; i < en; i++) plan_stage1(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i]);
+        for (int64_t i = b; i < en; i++) plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i], false);
     });
+    {   // df of the fuzzy unions first seen in this batch: counted on the device (sharded: summed over the shards by the caller)
+        B.pending.clear();
+        for (auto& P : plans) for (auto& r : P.rawTok) if (r.fz && r.fz->df.load() < 0) { bool dup = false; for (auto& x : B.pending) if (x.get() == r.fz.get()) { dup = true; break; } if (!dup) B.pending.push_back(r.fz); }
+        B.pendingCounts.assign(B.pending.size(), 0);
+        if (!B.pending.empty()) {
+            std::vector<uint32_t> mo(B.pending.size() + 1, 0); std::vector<int32_t> mm;
+            for (size_t v = 0; v < B.pending.size(); v++) { mm.insert(mm.end(), B.pending[v]->members.begin(), B.pending[v]->members.end()); mo[v + 1] = (uint32_t)mm.size(); }
+            int32_t rc = infx_union_counts(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), B.pendingCounts.data());
+            if (rc) { g_eerr = infx_last_error(); return rc; }
+        }
+    }
+    return INFX_OK;
+}
+
+// second half of planning: global df of the pending unions known
+static int32_t ph_plan_finish(infx_engine* e, infx_session* S, const uint32_t* globalUnionCounts) {
+    const HostIndex& ix = e->ix; const int threads = e->threads;
+    Batch& B = *S->batch; const uint32_t nq = B.nq;
+    std::vector<QueryPlan>& plans = S->lastPlans;
+    for (size_t v = 0; v < B.pending.size(); v++) B.pending[v]->df.store((int)globalUnionCounts[v]);
+    parallel_dyn(nq, threads, 8, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; i++) plan_finish(ix, plans[i]); });
     B.tPlanPar = now_ms() - B.t0;
     const int32_t sb = e->shardBase, se = e->shardBase + e->shardN;
     const bool sharded = e->nranks > 1;
@@ -205,7 +227,10 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
         termBase[i] = nterm; extraBase[i] = nextra;
         if (P.blank || P.unsupported || P.noTerms) continue;
         P.q.term_off = (uint32_t)nterm; nterm += P.terms.size();
-        for (size_t k = 0; k < P.terms.size(); k++) if (P.terms[k].term_id < 0) { size_t lo, hi; shard_slice(P.fuzzy[k]->docs, lo, hi); nextra += hi - lo; }
+        for (size_t k = 0; k < P.terms.size(); k++) if (P.terms[k].term_id < 0) {
+            if (P.terms[k].reserved == 1) nextra += P.fuzzy[k]->members.size();
+            else { size_t lo, hi; shard_slice(P.fuzzy[k]->docs, lo, hi); nextra += hi - lo; }
+        }
         B.devOf[i] = (int)B.dq.size(); B.dq.push_back(P.q); B.qmap.push_back(i);
     }
     if (nextra > 0xFFFFFFF0ull) return efail(INFX_ECAPACITY, "fuzzy unions of this batch exceed 2^32 postings; split the batch");
@@ -217,7 +242,11 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
             size_t xo = extraBase[i];
             for (size_t k = 0; k < P.terms.size(); k++) {
                 infx_term t = P.terms[k];
-                if (t.term_id < 0) {     // fuzzy union: global ids -> this shard's slice, rebased (its df / idf stay global)
+                if (t.term_id < 0 && t.reserved == 1) {     // member term ids: the union is formed on the device
+                    const auto& m = P.fuzzy[k]->members;
+                    t.extra_off = (uint32_t)xo; t.extra_len = (uint32_t)m.size();
+                    std::memcpy(B.extra.data() + xo, m.data(), m.size() * 4); xo += m.size();
+                } else if (t.term_id < 0) {     // host-built union: global ids -> this shard's slice, rebased (its df / idf stay global)
                     const auto& d = P.fuzzy[k]->docs; size_t lo, hi; shard_slice(d, lo, hi);
                     t.extra_off = (uint32_t)xo; t.extra_len = (uint32_t)(hi - lo);
                     for (size_t z = lo; z < hi; z++) B.extra[xo + (z - lo)] = d[z] - sb;
@@ -255,7 +284,11 @@ static int32_t ph_select(infx_engine* e, infx_session* S, const infx_counts* glo
         infx_last_candidates(S->stream, &S->s1Candidates);
         // B_alg(q) = sum_t df_t * 5 B (4 B for fuzzy virtual terms) + card(C_q) * 4 B + depth * 12 B   (this shard's slices)
         uint64_t ab = 0;
-        for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
+        for (auto& t : B.dterms) {
+            if (t.term_id >= 0) ab += (uint64_t)e->shardTermLen(t.term_id) * 5ull;
+            else if (t.reserved == 1) { for (uint32_t m = 0; m < t.extra_len; m++) ab += (uint64_t)e->shardTermLen(B.extra[t.extra_off + m]) * 4ull; }
+            else ab += (uint64_t)t.extra_len * 4ull;
+        }
         uint64_t nh = 0; for (uint32_t c : hitCount) nh += c;
         S->algBytes = ab + S->s1Candidates * 4ull + nh * 12ull;
     }
@@ -442,6 +475,7 @@ static int32_t search_batch_impl(infx_engine* e, infx_session* S, uint32_t nq, c
     if (!e->indexed) { for (uint32_t i = 0; i < nq; i++) out_counts[i] = 0; return INFX_OK; }   // Result.MakeEmptyResult(), SearchEngine.cs:261-262
     if (e->nranks > 1) return efail(INFX_EINVAL, "sharded engine: drive the phase API (infx_session_phase1..4) with the collectives in between");
     int32_t rc = ph_plan(e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
+    rc = ph_plan_finish(e, S, S->batch->pendingCounts.data()); if (rc) return rc;
     rc = ph_accumulate(e, S); if (rc) return rc;
     rc = ph_select(e, S, S->batch->counts.data()); if (rc) return rc;
     rc = ph_stage2(e, S, 1, S->lastHits.data(), S->lastHitCount.data(), max_results, enable_coverage); if (rc) return rc;
@@ -476,9 +510,20 @@ int32_t infx_engine_set_shard(infx_engine* e, int32_t rank, int32_t nranks) {
     e->rank = rank; e->nranks = nranks; return INFX_OK;
 }
 int32_t infx_engine_shard_info(infx_engine* e, int32_t* base, int32_t* n) { if (!e) return INFX_EINVAL; if (base) *base = e->shardBase; if (n) *n = e->shardN; return INFX_OK; }
-int32_t infx_session_phase1(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, uint32_t* ndev) {
+int32_t infx_session_phase0(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, uint32_t* nunions) {
     if (!S) return efail(INFX_EINVAL, "null session");
     int32_t rc = ph_plan(S->e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
+    if (nunions) *nunions = (uint32_t)S->batch->pending.size();
+    return INFX_OK;
+}
+int32_t infx_session_union_counts(infx_session* S, uint32_t* counts) {   // this shard's |union| of every pending fuzzy virtual term
+    if (!S || !counts) return efail(INFX_EINVAL, "null");
+    std::memcpy(counts, S->batch->pendingCounts.data(), S->batch->pendingCounts.size() * 4); return INFX_OK;
+}
+int32_t infx_session_phase1(infx_session* S, const uint32_t* global_union_counts, uint32_t* ndev) {
+    if (!S) return efail(INFX_EINVAL, "null session");
+    static const uint32_t zero = 0;
+    int32_t rc = ph_plan_finish(S->e, S, global_union_counts ? global_union_counts : &zero); if (rc) return rc;
     rc = ph_accumulate(S->e, S); if (rc) return rc;
     if (ndev) *ndev = S->batch->nd;
     return INFX_OK;

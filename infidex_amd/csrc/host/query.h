@@ -112,13 +112,37 @@ inline int match_ld1(const HostIndex& ix, uview q, std::vector<int>& out, int ca
 }
 
 // ---- Stage-1 plan -----------------------------------------------------------------------------------------------------------
-struct FuzzyUnion { std::vector<int32_t> docs; };
+// A fuzzy virtual term (ExpandMissingTerm): the LD1-matched member terms; its df = |union of their doc sets| is counted on the
+// device (infx_union_counts) and cached with the members per misspelt word, like the reference's LruCache (VectorModel.cs:42).
+struct FuzzyUnion {
+    std::vector<int32_t> members;        // index term ids (df > 0), in trie pre-order
+    std::atomic<int> df{-1};             // -1 = not counted yet
+    bool materialised = false;           // host-built union (no device, or more than FUZZY_MAX_MEMBERS members)
+    std::vector<int32_t> docs;           // only when materialised
+};
+constexpr size_t FUZZY_MAX_MEMBERS = 512;
 struct FuzzyCache {
     std::atomic<long long> fuzzyNs{0}, fuzzyCalls{0}, fuzzyDocs{0}, ld1Ns{0};   // instrumentation (INFX_DEBUG)
     std::mutex mu; std::unordered_map<std::u16string, std::shared_ptr<FuzzyUnion>> map;
     std::shared_ptr<FuzzyUnion> get(const ustr& k) { std::lock_guard<std::mutex> l(mu); auto it = map.find(k); return it == map.end() ? nullptr : it->second; }
-    void put(const ustr& k, std::shared_ptr<FuzzyUnion> v) { std::lock_guard<std::mutex> l(mu); if (map.size() > 100000) map.clear(); map[k] = v; }
+    std::shared_ptr<FuzzyUnion> put(const ustr& k, std::shared_ptr<FuzzyUnion> v) {   // first writer wins
+        std::lock_guard<std::mutex> l(mu); if (map.size() > 100000) map.clear();
+        auto r = map.emplace(k, v); return r.first->second;
+    }
 };
+inline void materialise_union(const HostIndex& ix, FuzzyUnion& fz) {    // union of the (sorted) member lists: pairwise merges, smallest first
+    std::vector<std::pair<const int32_t*, size_t>> lists;
+    for (int id : fz.members) lists.push_back({ix.terms.doc.data() + ix.terms.off[id], (size_t)ix.terms.len((uint32_t)id)});
+    std::sort(lists.begin(), lists.end(), [](auto& a, auto& c) { return a.second < c.second; });
+    std::vector<int32_t> acc, tmp;
+    for (auto& l : lists) {
+        if (acc.empty()) { acc.assign(l.first, l.first + l.second); continue; }
+        tmp.resize(acc.size() + l.second);
+        tmp.resize(std::set_union(acc.begin(), acc.end(), l.first, l.first + l.second, tmp.begin()) - tmp.begin());
+        acc.swap(tmp);
+    }
+    fz.docs.swap(acc); fz.materialised = true; fz.df.store((int)fz.docs.size());
+}
 
 struct QueryPlan {
     bool blank = false, unsupported = false;
@@ -129,6 +153,9 @@ struct QueryPlan {
     std::vector<std::shared_ptr<FuzzyUnion>> fuzzy;  // per term (null for index terms)
     infx_query q{};
     bool noTerms = false;
+    struct Raw { int id; ustr text; std::shared_ptr<FuzzyUnion> fz; };
+    std::vector<Raw> rawTok;                          // between plan_tokens and plan_finish
+    int depth = 0;
 };
 
 inline void analyze_query(uview text, int minIndexSize, bool& canUse, bool& mixed, ustr& longWords) {   // QueryAnalyzer.cs:10-54
@@ -140,8 +167,10 @@ inline void analyze_query(uview text, int minIndexSize, bool& canUse, bool& mixe
     if (shortCnt > 0 && longCnt > 0) mixed = true;
 }
 
-inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int depth, QueryPlan& P) {
-    P = QueryPlan();
+// Pass 1: text preparation, term lookup, LD1 member lists of unknown words (df of new unions still pending).
+// hostUnions: build the unions on the host (engines without a device: planning introspection only).
+inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int depth, QueryPlan& P, bool hostUnions) {
+    P = QueryPlan(); P.depth = depth;
     size_t b = 0, e = raw.size();
     while (b < e && is_ws(raw[b])) b++;
     while (e > b && is_ws(raw[e - 1])) e--;
@@ -157,10 +186,10 @@ inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
     { bool ws = true; for (u16 c : P.tfidfQuery) if (!is_ws(c)) { ws = false; break; } if (ws) P.tfidfQuery = P.searchText; }
 
     // raw tokens: words first, then n-grams of the padded text; at most 128 (VectorModel.cs:381,407)
-    struct Raw { int id; ustr text; };
-    std::vector<Raw> rawTok;
+    using Raw = QueryPlan::Raw;
+    std::vector<Raw>& rawTok = P.rawTok;
     ustr text = normalize(P.tfidfQuery);
-    auto visit = [&](uview s) { if (rawTok.size() >= 128) return; int64_t id = ix.terms.keys.find(s); if (id >= 0) rawTok.push_back({(int)id, ustr()}); else rawTok.push_back({-1, ustr(s)}); };
+    auto visit = [&](uview s) { if (rawTok.size() >= 128) return; int64_t id = ix.terms.keys.find(s); if (id >= 0) rawTok.push_back({(int)id, ustr(), nullptr}); else rawTok.push_back({-1, ustr(s), nullptr}); };
     for_each_word(text, [&](int off, int len) { if (len >= n) visit(uview(text.data() + off, len)); });
     ustr padded((size_t)ix.cfg.startPad, (u16)0xFFFF); padded += text; padded.append((size_t)ix.cfg.stopPad, (u16)0xFFFE);
     if ((int)padded.size() >= n)
@@ -171,6 +200,30 @@ inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
     std::sort(rawTok.begin(), rawTok.end(), [](const Raw& a, const Raw& c) { return a.id != c.id ? a.id < c.id : a.text < c.text; });
     rawTok.erase(std::unique(rawTok.begin(), rawTok.end(), [](const Raw& a, const Raw& c) { return a.id == c.id && a.text == c.text; }), rawTok.end());
 
+    for (auto& r : rawTok) {
+        if (r.id >= 0 || r.text.size() < 4) continue;      // ExpandMissingTerm (VectorModel.cs:643-743): unknown words of length >= 4
+        auto fz = fc.get(r.text);
+        if (!fz) {
+            auto tF0 = std::chrono::steady_clock::now();
+            std::vector<int> m; match_ld1(ix, r.text, m, 1024);
+            fc.ld1Ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tF0).count();
+            auto nf = std::make_shared<FuzzyUnion>();
+            for (int id : m) if (ix.df[id] > 0 && ix.terms.len((uint32_t)id)) nf->members.push_back(id);
+            if (nf->members.empty()) nf->df.store(0);
+            else if (hostUnions || nf->members.size() > FUZZY_MAX_MEMBERS) materialise_union(ix, *nf);
+            fz = fc.put(r.text, nf);
+            fc.fuzzyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tF0).count();
+            fc.fuzzyCalls++;
+        }
+        r.fz = fz;
+    }
+}
+
+// Pass 2 (every union's df known): idf / maxScore, candidate-selection mode and tier roles.
+inline void plan_finish(const HostIndex& ix, QueryPlan& P) {
+    if (P.blank || P.unsupported) return;
+    const int depth = P.depth;
+    auto& rawTok = P.rawTok;
     const int N = ix.N;
     const float avgdl = ix.avgdl > 0.f ? ix.avgdl : 1.f;
     struct TI { int termId; int df; float idf, maxScore; std::shared_ptr<FuzzyUnion> fz; };
@@ -178,32 +231,7 @@ inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
     for (auto& r : rawTok) {
         int df = 0; std::shared_ptr<FuzzyUnion> fz;
         if (r.id >= 0) df = ix.df[r.id];
-        else if (r.text.size() >= 4) {      // ExpandMissingTerm (VectorModel.cs:643-743)
-            fz = fc.get(r.text);
-            if (!fz) {
-                auto tF0 = std::chrono::steady_clock::now();
-                std::vector<int> m; match_ld1(ix, r.text, m, 1024);
-                fc.ld1Ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tF0).count();
-                // union of the matched terms' (sorted) posting lists: pairwise merges, smallest lists first
-                std::vector<std::pair<const int32_t*, size_t>> lists;
-                for (int id : m) if (ix.df[id] > 0 && ix.terms.len((uint32_t)id)) lists.push_back({ix.terms.doc.data() + ix.terms.off[id], (size_t)ix.terms.len((uint32_t)id)});
-                std::sort(lists.begin(), lists.end(), [](auto& a, auto& c) { return a.second < c.second; });
-                fz = std::make_shared<FuzzyUnion>();
-                std::vector<int32_t> acc, tmp;
-                for (auto& l : lists) {
-                    if (acc.empty()) { acc.assign(l.first, l.first + l.second); continue; }
-                    tmp.resize(acc.size() + l.second);
-                    tmp.resize(std::set_union(acc.begin(), acc.end(), l.first, l.first + l.second, tmp.begin()) - tmp.begin());
-                    acc.swap(tmp);
-                }
-                fz->docs.swap(acc);
-                fc.put(r.text, fz);
-                fc.fuzzyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tF0).count();
-                fc.fuzzyCalls++; fc.fuzzyDocs += (long long)fz->docs.size();
-            }
-            df = (int)fz->docs.size();
-            if (df == 0) fz = nullptr;
-        }
+        else if (r.fz) { fz = r.fz; df = fz->df.load(); if (df <= 0) fz = nullptr; }
         if (df <= 0 || df > ix.cfg.stopTermLimit) continue;
         float idf = compute_idf(N, df);
         const float maxTf = 255.f, k1 = 1.2f, bb = 0.75f, delta = 1.0f;
@@ -217,7 +245,7 @@ inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
     for (int i = 0; i < nT; i++) {
         infx_term& t = P.terms[i]; std::memset(&t, 0, sizeof t);
         t.term_id = tis[i].termId; t.idf = tis[i].idf; t.max_score = tis[i].maxScore; P.fuzzy[i] = tis[i].fz;
-        if (tis[i].fz) t.extra_len = (uint32_t)tis[i].fz->docs.size();
+        if (tis[i].fz) { t.extra_len = (uint32_t)(tis[i].fz->materialised ? tis[i].fz->docs.size() : tis[i].fz->members.size()); t.reserved = tis[i].fz->materialised ? 0 : 1; }
     }
     infx_query& Q = P.q; std::memset(&Q, 0, sizeof Q);
     Q.num_terms = (uint32_t)nT; Q.depth = depth; Q.prefix_set = -1;
@@ -276,6 +304,12 @@ inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
             sel++;
         }
     }
+}
+
+inline void plan_stage1(const HostIndex& ix, FuzzyCache& fc, uview raw, int depth, QueryPlan& P) {   // host-only (introspection)
+    plan_tokens(ix, fc, raw, depth, P, true);
+    for (auto& r : P.rawTok) if (r.fz && r.fz->df.load() < 0) materialise_union(ix, *r.fz);
+    plan_finish(ix, P);
 }
 
 // ---- WordMatcher lookups ---------------------------------------------------------------------------------------------------

@@ -137,6 +137,7 @@ struct infx_stream {
     void* dBlockOut = nullptr; size_t capBlockOut = 0;
     void* dBlockOutHi = nullptr; size_t capBlockOutHi = 0;
     void* dQBytes = nullptr; size_t capQBytes = 0;
+    void* dUOffs = nullptr; size_t capUOffs = 0; void* dUMem = nullptr; size_t capUMem = 0; void* dUCnt = nullptr; size_t capUCnt = 0;
     void* dCounts = nullptr; size_t capCounts = 0;
     void* dCovQ = nullptr; size_t capCovQ = 0;
     void* dCovC = nullptr; size_t capCovC = 0;
@@ -161,8 +162,12 @@ static int32_t grow(void** p, size_t* cap, size_t need) {
 }
 #define GROW(p, cap, need) do { int32_t rc_ = grow((void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)
 
+template <int R> static void launch_union(infx_stream* s, uint32_t nv, const uint32_t* dOffs, const int32_t* dMembers, uint32_t* dCounts) {
+    uint64_t blocks = (uint64_t)nv * s->ix->d.nRanges;
+    k_union_count<R><<<dim3((unsigned)blocks), dim3(WAVE), 0, s->st>>>(s->ix->d, dOffs, dMembers, nv, dCounts);
+}
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT) {
-    size_t lds = (size_t)(R / 32) * 8 + (size_t)ACC_CAP * 8 + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
+    size_t lds = (size_t)(R / 32) * 8 + (size_t)ACC_CAP * 9 + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
     uint64_t blocks = (uint64_t)nq * s->ix->d.nRanges;
     k_accumulate<R><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
                                                                            (const int32_t*)s->dExtra, nq, ar, maxT);
@@ -293,7 +298,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
 void infx_stream_destroy(infx_stream* s) {
     if (!s) return;
     hipSetDevice(s->ix->cfg.device);
-    void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dCounts,
+    void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow};
     for (void* p : ps) if (p) hipFree(p);
     hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1};
@@ -310,8 +315,10 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     if (nq == 0) return INFX_OK;
     HIPCHK(hipSetDevice(ix->cfg.device));
     if ((uint64_t)nq * ix->d.nRanges > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nq * nRanges exceeds the grid limit; split the batch%s");
-    // translate + capacity bound
-    std::vector<DevQuery> dq(nq); std::vector<DevTerm> dt(nterms);
+    // translate + capacity bound.  A virtual term given as a MEMBER LIST (infx_term.reserved == 1: extra_docs[extra_off..+len) are index
+    // term ids) is expanded into one device entry per member, all sharing the term's idf / role / rank and a dedupe group.
+    std::vector<DevQuery> dq(nq); std::vector<DevTerm> dt; dt.reserve(nterms + 64);
+    std::vector<int32_t> termOfEntry; termOfEntry.reserve(nterms + 64);
     std::vector<unsigned long long> qbase((size_t)nq + 1);
     unsigned long long bound = 0; int maxT = 1;
     for (uint32_t i = 0; i < nq; i++) {
@@ -320,25 +327,39 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
         if (Q.depth <= 0 || Q.depth > ix->cfg.max_depth) return fail(INFX_EINVAL, "query depth exceeds infx_config.max_depth%s");
         if (Q.mode < INFX_MODE_PREFIX || Q.mode > INFX_MODE_AND) return fail(INFX_EINVAL, "bad query mode%s");
         if (Q.prefix_set >= (int32_t)ix->d.nSets || (Q.mode == INFX_MODE_PREFIX && Q.prefix_set < 0)) return fail(INFX_EINVAL, "bad prefix set%s");
-        dq[i] = DevQuery{Q.term_off, Q.num_terms, Q.mode, Q.prefix_set, Q.depth, Q.n_and};
-        maxT = std::max(maxT, (int)Q.num_terms);
-        unsigned long long qb = 0;
+        const uint32_t entryOff = (uint32_t)dt.size();
+        unsigned long long qb = 0; int group = 0;
         for (uint32_t k = 0; k < Q.num_terms; k++) {
             const infx_term& tm = terms[Q.term_off + k];
-            DevTerm& D = dt[Q.term_off + k];
-            D.idf = tm.idf; D.role = tm.role; D.rank = tm.rank; D.pad = 0;
+            const bool gen = (Q.mode == INFX_MODE_AND && (tm.role & (INFX_ROLE_S1 | INFX_ROLE_S2))) ||
+                             (Q.mode == INFX_MODE_DISJ && (tm.role & (INFX_ROLE_ELIGIBLE | INFX_ROLE_LOWQ)));
+            DevTerm D{}; D.idf = tm.idf; D.role = tm.role; D.rank = tm.rank; D.pad = 0;
             if (tm.term_id >= 0) {
                 if (tm.term_id >= ix->d.T) return fail(INFX_EINVAL, "term id out of range%s");
                 D.begin = ix->hPostOff[tm.term_id]; D.end = ix->hPostOff[tm.term_id + 1]; D.isVirtual = 0;
-                D.skip = 0;   // patched below from device table semantics: host mirrors the rule
+                dt.push_back(D); termOfEntry.push_back(tm.term_id);
+                if (gen) qb += D.end - D.begin;
+            } else if (tm.reserved == 1) {
+                if ((uint64_t)tm.extra_off + tm.extra_len > extra_n) return fail(INFX_EINVAL, "virtual term member list out of range%s");
+                if (++group > 255) return fail(INFX_ECAPACITY, "more than 255 fuzzy virtual terms in one query%s");
+                for (uint32_t m = 0; m < tm.extra_len; m++) {
+                    int32_t mt = extra_docs[tm.extra_off + m];
+                    if (mt < 0 || mt >= ix->d.T) return fail(INFX_EINVAL, "member term id out of range%s");
+                    DevTerm M = D; M.begin = ix->hPostOff[mt]; M.end = ix->hPostOff[mt + 1]; M.isVirtual = 2; M.pad = (uint8_t)group;
+                    dt.push_back(M); termOfEntry.push_back(mt);
+                    if (gen) qb += M.end - M.begin;
+                }
             } else {
                 if ((uint64_t)tm.extra_off + tm.extra_len > extra_n) return fail(INFX_EINVAL, "virtual term slice out of range%s");
                 D.begin = tm.extra_off; D.end = (uint64_t)tm.extra_off + tm.extra_len; D.isVirtual = 1; D.skip = 0xFFFFFFFFu;
+                dt.push_back(D); termOfEntry.push_back(-1);
+                if (gen) qb += D.end - D.begin;
             }
-            bool gen = (Q.mode == INFX_MODE_AND && (tm.role & (INFX_ROLE_S1 | INFX_ROLE_S2))) ||
-                       (Q.mode == INFX_MODE_DISJ && (tm.role & (INFX_ROLE_ELIGIBLE | INFX_ROLE_LOWQ)));
-            if (gen) qb += D.end - D.begin;
         }
+        const uint32_t nEntries = (uint32_t)dt.size() - entryOff;
+        if (nEntries > 2048) return fail(INFX_ECAPACITY, "query expands to more than 2048 posting lists (fuzzy member lists); materialise the union on the host%s");
+        dq[i] = DevQuery{entryOff, nEntries, Q.mode, Q.prefix_set, Q.depth, Q.n_and};
+        maxT = std::max(maxT, (int)nEntries);
         if (Q.mode == INFX_MODE_PREFIX) qb = ix->hPsOff[Q.prefix_set + 1] - ix->hPsOff[Q.prefix_set];
         qbase[i] = bound;
         bound += std::min<unsigned long long>(qb, (unsigned long long)ix->d.N);
@@ -355,7 +376,7 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
         s->arCap = n;
     }
     GROW(s->dQueries, s->capQueries, nq * sizeof(DevQuery));
-    GROW(s->dTerms, s->capTerms, std::max<size_t>(1, nterms) * sizeof(DevTerm));
+    GROW(s->dTerms, s->capTerms, std::max<size_t>(1, dt.size()) * sizeof(DevTerm));
     GROW(s->dExtra, s->capExtra, std::max<size_t>(1, extra_n) * 4);
     GROW(s->dBlockOut, s->capBlockOut, ((size_t)nq + 1) * 8);      // qBase
     GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * 4);        // qCursor
@@ -373,10 +394,10 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
             mirrors.emplace_back(ix, std::move(v)); skipMirror = &mirrors.back().second;
         }
     }
-    for (uint32_t i = 0; i < nterms; i++) if (!dt[i].isVirtual) dt[i].skip = (*skipMirror)[terms[i].term_id];
+    for (size_t i = 0; i < dt.size(); i++) if (termOfEntry[i] >= 0) dt[i].skip = (*skipMirror)[termOfEntry[i]];
 
     HIPCHK(hipMemcpyAsync(s->dQueries, dq.data(), nq * sizeof(DevQuery), hipMemcpyHostToDevice, s->st));
-    if (nterms) HIPCHK(hipMemcpyAsync(s->dTerms, dt.data(), nterms * sizeof(DevTerm), hipMemcpyHostToDevice, s->st));
+    if (!dt.empty()) HIPCHK(hipMemcpyAsync(s->dTerms, dt.data(), dt.size() * sizeof(DevTerm), hipMemcpyHostToDevice, s->st));
     if (extra_n) HIPCHK(hipMemcpyAsync(s->dExtra, extra_docs, (size_t)extra_n * 4, hipMemcpyHostToDevice, s->st));
     HIPCHK(hipMemcpyAsync(s->dBlockOut, qbase.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, s->st));
     HIPCHK(hipMemsetAsync(s->dQBytes, 0, (size_t)nq * 8, s->st));
@@ -524,6 +545,34 @@ int32_t infx_last_timings(infx_stream* s, float* a, float* b, float* c) {
     if (s->timedSel) hipEventElapsedTime(&s->msSel, s->evS0, s->evS1);
     if (s->timedCov) hipEventElapsedTime(&s->msCov, s->evC0, s->evC1);
     if (a) *a = s->msAcc; if (b) *b = s->msSel; if (c) *c = s->msCov;
+    return INFX_OK;
+}
+int32_t infx_union_counts(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out) {
+    if (!s || (nv && (!member_offs || !members || !counts_out))) return fail(INFX_EINVAL, "null argument%s");
+    if (nv == 0) return INFX_OK;
+    infx_index* ix = s->ix;
+    if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    if ((uint64_t)nv * ix->d.nRanges > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nv * nRanges exceeds the grid limit%s");
+    const uint32_t nm = member_offs[nv];
+    for (uint32_t i = 0; i < nm; i++) if (members[i] < 0 || members[i] >= ix->d.T) return fail(INFX_EINVAL, "member term id out of range%s");
+    GROW(s->dUOffs, s->capUOffs, ((size_t)nv + 1) * 4);
+    GROW(s->dUMem, s->capUMem, std::max<size_t>(1, nm) * 4);
+    GROW(s->dUCnt, s->capUCnt, (size_t)nv * 4);
+    HIPCHK(hipMemcpyAsync(s->dUOffs, member_offs, ((size_t)nv + 1) * 4, hipMemcpyHostToDevice, s->st));
+    if (nm) HIPCHK(hipMemcpyAsync(s->dUMem, members, (size_t)nm * 4, hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemsetAsync(s->dUCnt, 0, (size_t)nv * 4, s->st));
+    switch (ix->d.R) {
+        case 512: launch_union<512>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
+        case 1024: launch_union<1024>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
+        case 2048: launch_union<2048>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
+        case 4096: launch_union<4096>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
+        case 8192: launch_union<8192>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
+        default: launch_union<16384>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(counts_out, s->dUCnt, (size_t)nv * 4, hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
     return INFX_OK;
 }
 int32_t infx_last_candidates(infx_stream* s, uint64_t* n) {

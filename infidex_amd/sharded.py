@@ -4,7 +4,8 @@ One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm
 Every rank indexes the whole corpus on the host (global df / avgdl / N, exactly like the reference's single index), uploads
 its contiguous doc range, and runs each batch as four phases of the C++ engine with three small collectives in between:
 
-    phase1  plan + k_accumulate                      -> all-reduce(sum)  class histograms   (Exchange 1: tier decisions, quirk Q11)
+    phase0  text prep, LD1 member lists, k_union_count -> all-reduce(sum)  |union| of new fuzzy virtual terms (Exchange 1b)
+    phase1  idf/roles + k_accumulate                 -> all-reduce(sum)  class histograms   (Exchange 1: tier decisions, quirk Q11)
     phase2  k_select with the GLOBAL counts          -> all-gather       per-shard top-`depth` (Exchange 2: the north-star collective)
     phase3  merge, Stage-2 prep, k_stage2 on OWNED candidates -> all-reduce(sum) of the disjoint 12-byte records
     phase4  final ordering / truncation (identical on every rank)
@@ -63,11 +64,22 @@ class ShardSession:
         self.L = engine.L
         self.s = Session(engine)
 
-    def phase1(self, arena, offs, depth):
-        nd = C.c_uint32(0)
+    def phase0(self, arena, offs, depth):
+        nu = C.c_uint32(0)
         self.nq = len(offs) - 1
         self.depth = depth
-        self.e._check(self.L.infx_session_phase1(self.s.h, self.nq, _p(arena, C.c_uint16), _p(offs, C.c_uint64), depth, C.byref(nd)))
+        self.e._check(self.L.infx_session_phase0(self.s.h, self.nq, _p(arena, C.c_uint16), _p(offs, C.c_uint64), depth, C.byref(nu)))
+        uc = np.zeros(max(nu.value, 1), np.uint32)
+        if nu.value:
+            self.e._check(self.L.infx_session_union_counts(self.s.h, _p(uc, C.c_uint32)))
+        return uc[:nu.value]
+
+    def phase1(self, global_union_counts):
+        nd = C.c_uint32(0)
+        guc = np.ascontiguousarray(global_union_counts, np.uint32)
+        if guc.size == 0:
+            guc = np.zeros(1, np.uint32)
+        self.e._check(self.L.infx_session_phase1(self.s.h, _p(guc, C.c_uint32), C.byref(nd)))
         self.nd = nd.value
         counts = np.zeros((max(self.nd, 1), INFX_NCLASS), np.uint32)
         if self.nd:
@@ -119,7 +131,9 @@ class ShardedSearcher:
 
     def search_packed(self, arena, offs, max_results=10, depth=500, enable_coverage=True):
         c = self.comm
-        counts = self.sess.phase1(arena, offs, depth)
+        uc = self.sess.phase0(arena, offs, depth)
+        guc = c.allreduce_sum_i32(uc) if uc.size else uc                                          # Exchange 1b: df of new fuzzy unions
+        counts = self.sess.phase1(guc)
         gcounts = c.allreduce_sum_i32(counts) if counts.size else counts                       # Exchange 1
         hits, hc = self.sess.phase2(gcounts)
         all_hits = c.allgather(hits) if hits.size else hits.reshape((c.world,) + hits.shape)      # Exchange 2 (RCCL all-gather of top-k)
@@ -135,7 +149,9 @@ class ShardedSearcher:
 def simulate_shards(sessions: Sequence[ShardSession], arena, offs, max_results=10, depth=500, enable_coverage=True):
     """Single-process lock-step simulation of W shards (e.g. W engines on ONE GPU): same phases, numpy instead of RCCL.
     Used by the GPU parity test to check that the sharded path reproduces the unsharded results."""
-    counts = [s.phase1(arena, offs, depth) for s in sessions]
+    ucs = [s.phase0(arena, offs, depth) for s in sessions]
+    guc = np.sum(np.stack(ucs).astype(np.uint64), axis=0).astype(np.uint32) if ucs[0].size else ucs[0]
+    counts = [s.phase1(guc) for s in sessions]
     g = np.sum(np.stack(counts).astype(np.uint64), axis=0).astype(np.uint32)
     ph2 = [s.phase2(g) for s in sessions]
     all_hits = np.stack([h for h, _ in ph2]); all_hc = np.stack([c for _, c in ph2])
