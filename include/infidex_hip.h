@@ -86,7 +86,8 @@ typedef struct infx_term {
     uint8_t  rank;         /* disjunctive: position in the IDF-descending order among eligible terms (TieredCandidateSelector.cs:253) */
     uint16_t reserved;     /* virtual term only: 0 = extra_docs[extra_off..+len) are the union's doc ids (shard-local, ascending);
                               1 = they are the MEMBER TERM IDS (<= LD1 matches, VectorModel.cs:660-683): the union is formed on the
-                              device (one posting stream per member, each document counted once), its df comes from infx_union_counts */
+                              device inside the accumulate launch (one posting stream per member, each document counted once);
+                              2 = extra_off is the index of a union materialised on the device by the last infx_union_build */
 } infx_term;
 
 #define INFX_ROLE_AND      1   /* AND mode: member of terms[0..n-2] (everything but the lowest-IDF term) */
@@ -128,9 +129,11 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
 int32_t infx_stage1_batch(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
                           uint32_t extra_n, const int32_t* extra_docs, infx_hit* out, uint32_t* out_count);
 
-/* df of fuzzy virtual terms on this shard: counts_out[v] = |union of the doc sets of members[member_offs[v] .. member_offs[v+1])|
- * (RoaringBitmap.Create(allFuzzyDocs).Cardinality, VectorModel.cs:722-729). Sum over shards before computing idf (Exchange 1b). */
-int32_t infx_union_counts(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out);
+/* Fuzzy virtual terms on the device (ExpandMissingTerm, VectorModel.cs:643-743): for v in [0, nv) the union of the doc sets of
+ * members[member_offs[v] .. member_offs[v+1]) is materialised in HBM (ascending, shard-local ids) and counts_out[v] = its
+ * cardinality on this shard (RoaringBitmap.Cardinality, :722-729; sum over shards for the global df — Exchange 1b). The unions stay
+ * valid on this stream until the next infx_union_build and are referenced by infx_term {term_id -1, reserved 2, extra_off v}. */
+int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out);
 
 /* ---- Stage 2 ------------------------------------------------------------------------------------------------- */
 /* CoverageQueryContext (Coverage/CoverageEngine.cs:9-43) of one query, prepared on the host (PrepareQuery :61-126). */

@@ -43,7 +43,7 @@ struct Batch {
     std::vector<infx_counts> counts;
     std::vector<PerQ> pq;
     std::vector<uint32_t> localIdx;     // local Stage-2 candidates -> position in lastCands
-    std::vector<std::shared_ptr<FuzzyUnion>> pending; std::vector<uint32_t> pendingCounts;   // unions whose df this batch counts
+    std::vector<std::shared_ptr<FuzzyUnion>> pending; std::vector<uint32_t> pendingCounts; std::unordered_map<const FuzzyUnion*, uint32_t> unionIdx;   // unions whose df this batch counts
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tPlanPar = 0;
 };
 
@@ -191,16 +191,17 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; i++) plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i], false);
     });
-    {   // df of the fuzzy unions first seen in this batch: counted on the device (sharded: summed over the shards by the caller)
-        B.pending.clear();
-        for (auto& P : plans) for (auto& r : P.rawTok) if (r.fz && r.fz->df.load() < 0) { bool dup = false; for (auto& x : B.pending) if (x.get() == r.fz.get()) { dup = true; break; } if (!dup) B.pending.push_back(r.fz); }
-        B.pendingCounts.assign(B.pending.size(), 0);
-        if (!B.pending.empty()) {
-            std::vector<uint32_t> mo(B.pending.size() + 1, 0); std::vector<int32_t> mm;
-            for (size_t v = 0; v < B.pending.size(); v++) { mm.insert(mm.end(), B.pending[v]->members.begin(), B.pending[v]->members.end()); mo[v + 1] = (uint32_t)mm.size(); }
-            int32_t rc = infx_union_counts(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), B.pendingCounts.data());
-            if (rc) { g_eerr = infx_last_error(); return rc; }
+    {   // every fuzzy union this batch uses is materialised on the device (this shard's slice); |union| = its df (sharded:
+        // summed over the shards by the caller)
+        B.pending.clear(); B.unionIdx.clear();
+        for (auto& P : plans) for (auto& r : P.rawTok) if (r.fz && !r.fz->materialised) {
+            if (B.unionIdx.emplace(r.fz.get(), (uint32_t)B.pending.size()).second) B.pending.push_back(r.fz);
         }
+        B.pendingCounts.assign(B.pending.size(), 0);
+        std::vector<uint32_t> mo(B.pending.size() + 1, 0); std::vector<int32_t> mm;
+        for (size_t v = 0; v < B.pending.size(); v++) { mm.insert(mm.end(), B.pending[v]->members.begin(), B.pending[v]->members.end()); mo[v + 1] = (uint32_t)mm.size(); }
+        int32_t rc = infx_union_build(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), B.pendingCounts.data());
+        if (rc) { g_eerr = infx_last_error(); return rc; }
     }
     return INFX_OK;
 }
@@ -228,7 +229,7 @@ static int32_t ph_plan_finish(infx_engine* e, infx_session* S, const uint32_t* g
         if (P.blank || P.unsupported || P.noTerms) continue;
         P.q.term_off = (uint32_t)nterm; nterm += P.terms.size();
         for (size_t k = 0; k < P.terms.size(); k++) if (P.terms[k].term_id < 0) {
-            if (P.terms[k].reserved == 1) nextra += P.fuzzy[k]->members.size();
+            if (P.terms[k].reserved == 1) continue;
             else { size_t lo, hi; shard_slice(P.fuzzy[k]->docs, lo, hi); nextra += hi - lo; }
         }
         B.devOf[i] = (int)B.dq.size(); B.dq.push_back(P.q); B.qmap.push_back(i);
@@ -242,10 +243,9 @@ static int32_t ph_plan_finish(infx_engine* e, infx_session* S, const uint32_t* g
             size_t xo = extraBase[i];
             for (size_t k = 0; k < P.terms.size(); k++) {
                 infx_term t = P.terms[k];
-                if (t.term_id < 0 && t.reserved == 1) {     // member term ids: the union is formed on the device
-                    const auto& m = P.fuzzy[k]->members;
-                    t.extra_off = (uint32_t)xo; t.extra_len = (uint32_t)m.size();
-                    std::memcpy(B.extra.data() + xo, m.data(), m.size() * 4); xo += m.size();
+                if (t.term_id < 0 && t.reserved == 1) {     // union materialised on the device by ph_plan
+                    const uint32_t v = B.unionIdx.at(P.fuzzy[k].get());
+                    t.reserved = 2; t.extra_off = v; t.extra_len = B.pendingCounts[v];
                 } else if (t.term_id < 0) {     // host-built union: global ids -> this shard's slice, rebased (its df / idf stay global)
                     const auto& d = P.fuzzy[k]->docs; size_t lo, hi; shard_slice(d, lo, hi);
                     t.extra_off = (uint32_t)xo; t.extra_len = (uint32_t)(hi - lo);
@@ -286,7 +286,6 @@ static int32_t ph_select(infx_engine* e, infx_session* S, const infx_counts* glo
         uint64_t ab = 0;
         for (auto& t : B.dterms) {
             if (t.term_id >= 0) ab += (uint64_t)e->shardTermLen(t.term_id) * 5ull;
-            else if (t.reserved == 1) { for (uint32_t m = 0; m < t.extra_len; m++) ab += (uint64_t)e->shardTermLen(B.extra[t.extra_off + m]) * 4ull; }
             else ab += (uint64_t)t.extra_len * 4ull;
         }
         uint64_t nh = 0; for (uint32_t c : hitCount) nh += c;
@@ -308,10 +307,15 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
     std::vector<infx_cov_query> covQ(nq);
     std::vector<int32_t> covErr(nq, 0);
     const bool covEnabled = ix.cfg.enableCoverage && enable_coverage;
+    static const bool dbg = getenv("INFX_DEBUG") != nullptr;
+    std::atomic<long long> nsMerge{0}, nsWm{0}, nsSel{0}, nsCovQ{0}, nsPush{0};
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         WmResult wm; std::vector<int32_t> sortedTop, overlap, uniq; std::vector<infx_hit> merged;
         for (int64_t i = b; i < en; i++) {
             QueryPlan& P = plans[i]; PerQ& Sq = B.pq[i];
+            auto tA = tick();
             if (P.blank || P.unsupported) { Sq.done = true; continue; }
             int j = B.devOf[i];
             if (j >= 0) {
@@ -337,9 +341,13 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
             bool skipCov = isShort && shortCount > 500;
             if (!covEnabled || skipCov) { Sq.done = true; continue; }
             Sq.runCov = true;
+            if (dbg) nsMerge += since(tA);
+            auto tB = tick();
             // ---- ExecuteCoverageStage preparation ----
             wm_collect(ix, st, true, wm);
             Sq.wmAny = wm.any;
+            if (dbg) nsWm += since(tB);
+            auto tC = tick();
             size_t ntop = std::min<size_t>(Sq.stage1.size(), (size_t)depth);
             sortedTop.assign(Sq.stage1Doc.begin(), Sq.stage1Doc.begin() + ntop);
             std::sort(sortedTop.begin(), sortedTop.end());
@@ -353,50 +361,85 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
             for (size_t k = 0; k < ntop && nf < 2; k++) first2[nf++] = Sq.stage1Doc[k];
             for (size_t k = 0; k < uniq.size() && nf < 2; k++) first2[nf++] = uniq[k];
             Sq.idx0 = first2[0]; Sq.idx1 = first2[1];
+            if (dbg) nsSel += since(tC);
+            auto tD = tick();
             covErr[i] = prepare_cov_query(ix, st, covQ[i]);
+            if (dbg) nsCovQ += since(tD);
             if (covErr[i]) continue;
+            auto tE = tick();
             auto& CL = candLocal[i];
             auto push = [&](int32_t doc, float base) { infx_cov_cand c{}; c.query = 0; c.doc = doc; c.base_score = base; c.want_lcs = (doc == first2[0] || doc == first2[1]) ? 1 : 0; CL.push_back(c); };
             for (int32_t d : overlap) push(d, 0.f);
             for (size_t k = 0; k < uniq.size() && k < wmLimit; k++) push(uniq[k], 0.f);
             float maxT = ntop ? Sq.stage1[0].score : 1.f;
             for (size_t k = 0; k < ntop; k++) push(Sq.stage1Doc[k], maxT > 0 ? Sq.stage1[k].score / maxT : 0.f);
+            if (dbg) nsPush += since(tE);
         }
     });
+    if (dbg) fprintf(stderr, "[infx] prep2 cpu-ms: merge %.1f wm %.1f select %.1f covq %.1f push %.1f | wall %.1f\n", nsMerge / 1e6, nsWm / 1e6, nsSel / 1e6, nsCovQ / 1e6, nsPush / 1e6, now_ms() - B.t2);
     for (uint32_t i = 0; i < nq; i++) if (covErr[i]) return efail(covErr[i], "query exceeds the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length)");
-    std::vector<infx_cov_query> covBatch; std::vector<infx_cov_cand>& cands = S->lastCands; cands.clear();
+    std::vector<infx_cov_query> covBatch; std::vector<infx_cov_cand>& cands = S->lastCands;
+    size_t ncand = 0;
     for (uint32_t i = 0; i < nq; i++) {
         PerQ& Sq = B.pq[i];
         if (!Sq.runCov) continue;
         Sq.covIndex = (int)covBatch.size(); covBatch.push_back(covQ[i]);
-        Sq.candOff = (uint32_t)cands.size(); Sq.candCount = (uint32_t)candLocal[i].size();
-        for (auto c : candLocal[i]) { c.query = (uint32_t)Sq.covIndex; cands.push_back(c); }
+        Sq.candOff = (uint32_t)ncand; Sq.candCount = (uint32_t)candLocal[i].size(); ncand += candLocal[i].size();
     }
+    cands.resize(ncand);
+    const int32_t sb = e->shardBase, se = e->shardBase + e->shardN;
+    const bool sharded = e->nranks > 1;
+    std::vector<uint64_t> tbytes(nq, 0);
+    parallel_dyn(nq, threads, 8, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; i++) {
+            PerQ& Sq = B.pq[i]; if (!Sq.runCov) continue;
+            infx_cov_cand* dst = cands.data() + Sq.candOff; uint64_t tb = 0;
+            for (size_t k = 0; k < candLocal[i].size(); k++) {
+                infx_cov_cand c = candLocal[i][k]; c.query = (uint32_t)Sq.covIndex; dst[k] = c;
+                if (c.doc >= sb && c.doc < se) tb += 2 * (ix.textOff[c.doc + 1] - ix.textOff[c.doc]);
+            }
+            tbytes[i] = tb;
+        }
+    });
+    S->s2TextBytes = 0; for (uint64_t x : tbytes) S->s2TextBytes += x;
     B.t3 = now_ms();
     // ---------------- Stage 2 on the GPU: the candidates whose text this shard holds ----------------
-    std::vector<infx_cov_out>& outs = S->lastOuts; outs.assign(cands.size(), infx_cov_out{});
-    const int32_t sb = e->shardBase, se = e->shardBase + e->shardN;
-    std::vector<infx_cov_cand> local; B.localIdx.clear();
-    S->s2Candidates = 0; S->s2TextBytes = 0;
-    for (size_t i = 0; i < cands.size(); i++) {
-        const infx_cov_cand& c = cands[i];
-        if (c.doc < sb || c.doc >= se) continue;
-        infx_cov_cand l = c; l.doc = c.doc - sb; local.push_back(l); B.localIdx.push_back((uint32_t)i);
-        S->s2TextBytes += 2 * (ix.textOff[c.doc + 1] - ix.textOff[c.doc]);
-    }
-    S->s2Candidates = local.size();
-    std::vector<infx_cov_out> lout(local.size());
-    std::vector<int32_t> lfeat;
-    if (e->cfg.want_features) { S->lastFeat.assign(cands.size() * INFX_NFEAT, 0); lfeat.assign(local.size() * INFX_NFEAT, 0); }
-    if (!local.empty()) {
-        int32_t rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)local.size(), local.data(), lout.data(), e->cfg.want_features ? lfeat.data() : nullptr);
-        if (rc) { g_eerr = infx_last_error(); return rc; }
-        infx_last_timings(S->stream, nullptr, nullptr, &S->msCov);
-        for (auto& o : lout) if (o.status) return efail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)");
-        for (size_t i = 0; i < local.size(); i++) {
-            outs[B.localIdx[i]] = lout[i];
-            if (e->cfg.want_features) std::memcpy(S->lastFeat.data() + (size_t)B.localIdx[i] * INFX_NFEAT, lfeat.data() + i * INFX_NFEAT, INFX_NFEAT * 4);
+    std::vector<infx_cov_out>& outs = S->lastOuts; outs.resize(cands.size());
+    const bool wantF = e->cfg.want_features != 0;
+    if (wantF) S->lastFeat.assign(cands.size() * INFX_NFEAT, 0);
+    B.localIdx.clear();
+    if (!sharded) {     // every candidate is local: score in place
+        S->s2Candidates = cands.size();
+        if (!cands.empty()) {
+            int32_t rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)cands.size(), cands.data(), outs.data(), wantF ? S->lastFeat.data() : nullptr);
+            if (rc) { g_eerr = infx_last_error(); return rc; }
+            infx_last_timings(S->stream, nullptr, nullptr, &S->msCov);
         }
+    } else {
+        std::fill(outs.begin(), outs.end(), infx_cov_out{});
+        std::vector<infx_cov_cand> local;
+        for (size_t i = 0; i < cands.size(); i++) {
+            const infx_cov_cand& c = cands[i];
+            if (c.doc < sb || c.doc >= se) continue;
+            infx_cov_cand l = c; l.doc = c.doc - sb; local.push_back(l); B.localIdx.push_back((uint32_t)i);
+        }
+        S->s2Candidates = local.size();
+        std::vector<infx_cov_out> lout(local.size());
+        std::vector<int32_t> lfeat;
+        if (wantF) lfeat.assign(local.size() * INFX_NFEAT, 0);
+        if (!local.empty()) {
+            int32_t rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)local.size(), local.data(), lout.data(), wantF ? lfeat.data() : nullptr);
+            if (rc) { g_eerr = infx_last_error(); return rc; }
+            infx_last_timings(S->stream, nullptr, nullptr, &S->msCov);
+            for (size_t i = 0; i < local.size(); i++) {
+                outs[B.localIdx[i]] = lout[i];
+                if (wantF) std::memcpy(S->lastFeat.data() + (size_t)B.localIdx[i] * INFX_NFEAT, lfeat.data() + i * INFX_NFEAT, INFX_NFEAT * 4);
+            }
+        }
+    }
+    {   std::atomic<int> bad{0};
+        parallel_for((int64_t)outs.size(), threads, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; i++) if (outs[i].status) { bad.store(1); break; } });
+        if (bad.load()) return efail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)");
     }
     B.t4 = now_ms();
     return INFX_OK;

@@ -20,30 +20,70 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <memory>
+#include <condition_variable>
+#include <mutex>
 
 namespace infx {
 
-template <class F> inline void parallel_for(int64_t n, int threads, F&& f) {   // f(begin, end, threadIndex)
-    if (threads <= 1 || n < 2) { f((int64_t)0, n, 0); return; }
-    std::vector<std::thread> th;
-    int64_t per = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; t++) {
-        int64_t b = t * per, e = std::min(n, b + per);
-        if (b >= e) break;
-        th.emplace_back([=, &f] { f(b, e, t); });
+// ---- host worker pool ------------------------------------------------------------------------------------------------
+// One process-wide pool (hardware threads - 1 workers; the calling thread always takes part).  A parallel region is a shared
+// chunk counter; idle workers join any region that still has chunks and a free slot, so several sessions preparing batches at
+// the same time share the cores instead of each spawning its own threads.
+struct Pool {
+    struct Region {
+        std::function<void(int64_t, int)> run;   // (chunk, slot)
+        int64_t nchunks = 0; int maxSlots = 1;
+        std::atomic<int64_t> next{0};
+        int slots = 1, working = 1;              // guarded by Pool::m
+        std::condition_variable done;
+    };
+    std::mutex m; std::condition_variable cv; std::vector<std::shared_ptr<Region>> regions; int nworkers = 0;
+    static Pool& get() { static Pool* p = new Pool(); return *p; }    // never destroyed: workers are detached
+    static bool& in_worker() { static thread_local bool w = false; return w; }
+    Pool() {
+        unsigned hc = std::thread::hardware_concurrency(); nworkers = hc > 1 ? (int)hc - 1 : 0;
+        for (int i = 0; i < nworkers; i++) std::thread([this] { worker(); }).detach();
     }
-    for (auto& x : th) x.join();
+    void worker() {
+        in_worker() = true;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            std::shared_ptr<Region> r; int slot = 0;
+            for (auto& x : regions) if (x->slots < x->maxSlots && x->next.load(std::memory_order_relaxed) < x->nchunks) { r = x; slot = x->slots++; x->working++; break; }
+            if (!r) { cv.wait(lk); continue; }
+            lk.unlock();
+            for (;;) { int64_t c = r->next.fetch_add(1); if (c >= r->nchunks) break; r->run(c, slot); }
+            lk.lock();
+            if (--r->working == 0) r->done.notify_all();
+        }
+    }
+    void run(int64_t nchunks, int maxSlots, std::function<void(int64_t, int)> fn) {
+        if (nchunks <= 0) return;
+        if (nchunks == 1 || maxSlots <= 1 || nworkers == 0 || in_worker()) { for (int64_t c = 0; c < nchunks; c++) fn(c, 0); return; }
+        auto r = std::make_shared<Region>(); r->run = std::move(fn); r->nchunks = nchunks; r->maxSlots = maxSlots;
+        { std::lock_guard<std::mutex> g(m); regions.push_back(r); }
+        cv.notify_all();
+        for (;;) { int64_t c = r->next.fetch_add(1); if (c >= nchunks) break; r->run(c, 0); }
+        std::unique_lock<std::mutex> lk(m);
+        r->working--;
+        r->done.wait(lk, [&] { return r->working == 0; });
+        for (size_t i = 0; i < regions.size(); i++) if (regions[i] == r) { regions.erase(regions.begin() + i); break; }
+    }
+};
+
+template <class F> inline void parallel_for(int64_t n, int threads, F&& f) {   // f(begin, end, partIndex): `threads` equal static parts
+    if (threads <= 1 || n < 2) { f((int64_t)0, n, 0); return; }
+    const int64_t per = (n + threads - 1) / threads;
+    const int64_t parts = (n + per - 1) / per;
+    Pool::get().run(parts, threads, [&](int64_t c, int) { f(c * per, std::min(n, (c + 1) * per), (int)c); });
 }
 
 // dynamic scheduling: items are handed out in small grains so that a few expensive items (fuzzy expansions, dense
 // WordMatcher words) do not serialise behind one thread
-template <class F> inline void parallel_dyn(int64_t n, int threads, int64_t grain, F&& f) {   // f(begin, end, threadIndex)
+template <class F> inline void parallel_dyn(int64_t n, int threads, int64_t grain, F&& f) {   // f(begin, end, slot), slot < threads
     if (threads <= 1 || n <= grain) { f((int64_t)0, n, 0); return; }
-    std::atomic<int64_t> next(0);
-    int nt = (int)std::min<int64_t>(threads, (n + grain - 1) / grain);
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; t++) th.emplace_back([&, t] { for (;;) { int64_t b = next.fetch_add(grain); if (b >= n) break; f(b, std::min(n, b + grain), t); } });
-    for (auto& x : th) x.join();
+    Pool::get().run((n + grain - 1) / grain, threads, [&](int64_t c, int slot) { f(c * grain, std::min(n, (c + 1) * grain), slot); });
 }
 
 // ---- string -> dense id table (open addressing, keys in an arena) -----------------------------------------------

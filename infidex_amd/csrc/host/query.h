@@ -210,7 +210,7 @@ inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
             auto nf = std::make_shared<FuzzyUnion>();
             for (int id : m) if (ix.df[id] > 0 && ix.terms.len((uint32_t)id)) nf->members.push_back(id);
             if (nf->members.empty()) nf->df.store(0);
-            else if (hostUnions || nf->members.size() > FUZZY_MAX_MEMBERS) materialise_union(ix, *nf);
+            else if (hostUnions) materialise_union(ix, *nf);
             fz = fc.put(r.text, nf);
             fc.fuzzyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tF0).count();
             fc.fuzzyCalls++;

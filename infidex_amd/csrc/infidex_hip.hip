@@ -138,6 +138,8 @@ struct infx_stream {
     void* dBlockOutHi = nullptr; size_t capBlockOutHi = 0;
     void* dQBytes = nullptr; size_t capQBytes = 0;
     void* dUOffs = nullptr; size_t capUOffs = 0; void* dUMem = nullptr; size_t capUMem = 0; void* dUCnt = nullptr; size_t capUCnt = 0;
+    void* dURange = nullptr; size_t capURange = 0; void* dUBase = nullptr; size_t capUBase = 0; void* dUDocs = nullptr; size_t capUDocs = 0;
+    std::vector<uint32_t> unionCount; std::vector<unsigned long long> unionBase{0};   // device-resident unions of the last infx_union_build
     void* dCounts = nullptr; size_t capCounts = 0;
     void* dCovQ = nullptr; size_t capCovQ = 0;
     void* dCovC = nullptr; size_t capCovC = 0;
@@ -162,15 +164,27 @@ static int32_t grow(void** p, size_t* cap, size_t need) {
 }
 #define GROW(p, cap, need) do { int32_t rc_ = grow((void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)
 
-template <int R> static void launch_union(infx_stream* s, uint32_t nv, const uint32_t* dOffs, const int32_t* dMembers, uint32_t* dCounts) {
+template <int R> static void launch_union(infx_stream* s, uint32_t nv, const uint32_t* dOffs, const int32_t* dMembers, uint32_t* dRangeCount,
+                                            const unsigned long long* dBase, int32_t* outDocs) {
     uint64_t blocks = (uint64_t)nv * s->ix->d.nRanges;
-    k_union_count<R><<<dim3((unsigned)blocks), dim3(WAVE), 0, s->st>>>(s->ix->d, dOffs, dMembers, nv, dCounts);
+    k_union<R><<<dim3((unsigned)blocks), dim3(WAVE), 0, s->st>>>(s->ix->d, dOffs, dMembers, nv, dRangeCount, dBase, outDocs);
+}
+static void launch_union_any(infx_stream* s, uint32_t nv, const uint32_t* dOffs, const int32_t* dMembers, uint32_t* dRangeCount,
+                             const unsigned long long* dBase, int32_t* outDocs) {
+    switch (s->ix->d.R) {
+        case 512: launch_union<512>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
+        case 1024: launch_union<1024>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
+        case 2048: launch_union<2048>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
+        case 4096: launch_union<4096>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
+        case 8192: launch_union<8192>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
+        default: launch_union<16384>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
+    }
 }
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT) {
     size_t lds = (size_t)(R / 32) * 8 + (size_t)ACC_CAP * 9 + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
     uint64_t blocks = (uint64_t)nq * s->ix->d.nRanges;
     k_accumulate<R><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, nq, ar, maxT);
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, nq, ar, maxT);
 }
 
 extern "C" {
@@ -298,7 +312,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
 void infx_stream_destroy(infx_stream* s) {
     if (!s) return;
     hipSetDevice(s->ix->cfg.device);
-    void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dCounts,
+    void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow};
     for (void* p : ps) if (p) hipFree(p);
     hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1};
@@ -339,6 +353,11 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
                 D.begin = ix->hPostOff[tm.term_id]; D.end = ix->hPostOff[tm.term_id + 1]; D.isVirtual = 0;
                 dt.push_back(D); termOfEntry.push_back(tm.term_id);
                 if (gen) qb += D.end - D.begin;
+            } else if (tm.reserved == 2) {     // union built on the device by the last infx_union_build: extra_off = its index
+                if (tm.extra_off >= s->unionCount.size()) return fail(INFX_EINVAL, "virtual term refers to a union that was not built%s");
+                D.begin = s->unionBase[tm.extra_off]; D.end = s->unionBase[tm.extra_off + 1]; D.isVirtual = 4 | 2; D.skip = 0xFFFFFFFFu;
+                dt.push_back(D); termOfEntry.push_back(-1);
+                if (gen) qb += D.end - D.begin;
             } else if (tm.reserved == 1) {
                 if ((uint64_t)tm.extra_off + tm.extra_len > extra_n) return fail(INFX_EINVAL, "virtual term member list out of range%s");
                 if (++group > 255) return fail(INFX_ECAPACITY, "more than 255 fuzzy virtual terms in one query%s");
@@ -378,6 +397,7 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     GROW(s->dQueries, s->capQueries, nq * sizeof(DevQuery));
     GROW(s->dTerms, s->capTerms, std::max<size_t>(1, dt.size()) * sizeof(DevTerm));
     GROW(s->dExtra, s->capExtra, std::max<size_t>(1, extra_n) * 4);
+    GROW(s->dUDocs, s->capUDocs, 4);
     GROW(s->dBlockOut, s->capBlockOut, ((size_t)nq + 1) * 8);      // qBase
     GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * 4);        // qCursor
     GROW(s->dQBytes, s->capQBytes, (size_t)nq * 8);
@@ -547,33 +567,37 @@ int32_t infx_last_timings(infx_stream* s, float* a, float* b, float* c) {
     if (a) *a = s->msAcc; if (b) *b = s->msSel; if (c) *c = s->msCov;
     return INFX_OK;
 }
-int32_t infx_union_counts(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out) {
+int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out) {
     if (!s || (nv && (!member_offs || !members || !counts_out))) return fail(INFX_EINVAL, "null argument%s");
+    s->unionCount.clear(); s->unionBase.assign(1, 0);
     if (nv == 0) return INFX_OK;
     infx_index* ix = s->ix;
     if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
-    if ((uint64_t)nv * ix->d.nRanges > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nv * nRanges exceeds the grid limit%s");
+    const int nR = ix->d.nRanges;
+    if ((uint64_t)nv * nR > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nv * nRanges exceeds the grid limit%s");
     const uint32_t nm = member_offs[nv];
     for (uint32_t i = 0; i < nm; i++) if (members[i] < 0 || members[i] >= ix->d.T) return fail(INFX_EINVAL, "member term id out of range%s");
     GROW(s->dUOffs, s->capUOffs, ((size_t)nv + 1) * 4);
     GROW(s->dUMem, s->capUMem, std::max<size_t>(1, nm) * 4);
     GROW(s->dUCnt, s->capUCnt, (size_t)nv * 4);
+    GROW(s->dURange, s->capURange, (size_t)nv * (nR + 1) * 4);
+    GROW(s->dUBase, s->capUBase, ((size_t)nv + 1) * 8);
     HIPCHK(hipMemcpyAsync(s->dUOffs, member_offs, ((size_t)nv + 1) * 4, hipMemcpyHostToDevice, s->st));
     if (nm) HIPCHK(hipMemcpyAsync(s->dUMem, members, (size_t)nm * 4, hipMemcpyHostToDevice, s->st));
-    HIPCHK(hipMemsetAsync(s->dUCnt, 0, (size_t)nv * 4, s->st));
-    switch (ix->d.R) {
-        case 512: launch_union<512>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
-        case 1024: launch_union<1024>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
-        case 2048: launch_union<2048>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
-        case 4096: launch_union<4096>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
-        case 8192: launch_union<8192>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
-        default: launch_union<16384>(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dUCnt); break;
-    }
+    launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, nullptr, nullptr);
+    k_union_scan<<<nv, 256, 0, s->st>>>((uint32_t*)s->dURange, nR, (uint32_t*)s->dUCnt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(counts_out, s->dUCnt, (size_t)nv * 4, hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));
-    return INFX_OK;
+    s->unionCount.assign(counts_out, counts_out + nv);
+    s->unionBase.assign((size_t)nv + 1, 0);
+    for (uint32_t v = 0; v < nv; v++) s->unionBase[v + 1] = s->unionBase[v] + counts_out[v];
+    GROW(s->dUDocs, s->capUDocs, std::max<size_t>(1, s->unionBase[nv]) * 4);
+    HIPCHK(hipMemcpyAsync(s->dUBase, s->unionBase.data(), ((size_t)nv + 1) * 8, hipMemcpyHostToDevice, s->st));
+    launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, (const unsigned long long*)s->dUBase, (int32_t*)s->dUDocs);
+    HIPCHK(hipGetLastError());
+    return INFX_OK;     // the write pass stays queued on the stream; infx_stage1_accumulate is ordered behind it
 }
 int32_t infx_last_candidates(infx_stream* s, uint64_t* n) {
     if (!s || !n) return fail(INFX_EINVAL, "null argument%s");
