@@ -43,7 +43,8 @@ typedef struct infx_stream infx_stream;   /* per-caller HIP stream + workspace *
 /* Replaces the constants of Bm25Scorer.cs:21-23 / ConfigurationParameters.cs:101-104. */
 typedef struct infx_config {
     int32_t device;          /* HIP device ordinal */
-    int32_t range_docs;      /* documents per LDS range block (power of two, 512..8192); 0 = default 1024 */
+    int32_t range_docs;      /* documents per LDS range block (power of two, 512..16384); 0 = chosen from the shard size at
+                                infx_upload_docs: 1024 below 256k documents ... 8192 from 4M documents */
     int32_t max_depth;       /* largest Query.CoverageDepth that will be used (default 500) */
     int32_t reserved;
 } infx_config;

@@ -44,7 +44,7 @@ struct Batch {
     std::vector<PerQ> pq;
     std::vector<uint32_t> localIdx;     // local Stage-2 candidates -> position in lastCands
     std::vector<std::shared_ptr<FuzzyUnion>> pending; std::vector<uint32_t> pendingCounts; std::unordered_map<const FuzzyUnion*, uint32_t> unionIdx;   // unions whose df this batch counts
-    double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tPlanPar = 0;
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tPlanPar = 0, tTok = 0, tUnion = 0;
 };
 
 struct infx_session {
@@ -188,9 +188,10 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
     g_eerr.clear();
     B.t0 = now_ms();
     std::vector<QueryPlan>& plans = S->lastPlans; plans.assign(nq, QueryPlan());
-    parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
+    parallel_dyn(nq, threads, 1, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; i++) plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i], false);
     });
+    B.tTok = now_ms() - B.t0;
     {   // every fuzzy union this batch uses is materialised on the device (this shard's slice); |union| = its df (sharded:
         // summed over the shards by the caller)
         B.pending.clear(); B.unionIdx.clear();
@@ -203,6 +204,7 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
         int32_t rc = infx_union_build(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), B.pendingCounts.data());
         if (rc) { g_eerr = infx_last_error(); return rc; }
     }
+    B.tUnion = now_ms() - B.t0;
     return INFX_OK;
 }
 
@@ -308,11 +310,11 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
     std::vector<int32_t> covErr(nq, 0);
     const bool covEnabled = ix.cfg.enableCoverage && enable_coverage;
     static const bool dbg = getenv("INFX_DEBUG") != nullptr;
-    std::atomic<long long> nsMerge{0}, nsWm{0}, nsSel{0}, nsCovQ{0}, nsPush{0};
+    std::atomic<long long> nsMerge{0}, nsWm{0}, nsSel{0}, nsCovQ{0}, nsPush{0}, nsSelMax{0};
     auto tick = [] { return std::chrono::steady_clock::now(); };
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
-        WmResult wm; std::vector<int32_t> sortedTop, overlap, uniq; std::vector<infx_hit> merged;
+        WmResult wm; std::vector<int32_t> sortedTop, overlap, uniq; std::vector<infx_hit> merged; std::vector<uint8_t> hitFlag; std::vector<uint32_t> sbase;
         for (int64_t i = b; i < en; i++) {
             QueryPlan& P = plans[i]; PerQ& Sq = B.pq[i];
             auto tA = tick();
@@ -352,7 +354,7 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
             sortedTop.assign(Sq.stage1Doc.begin(), Sq.stage1Doc.begin() + ntop);
             std::sort(sortedTop.begin(), sortedTop.end());
             overlap.clear();
-            if (wm.any) for (int32_t d : sortedTop) if (wm_contains(wm, d)) overlap.push_back(d);   // ascending
+            if (wm.any) { wm_contains_batch(wm, sortedTop.data(), (int)sortedTop.size(), hitFlag, sbase); for (size_t z = 0; z < sortedTop.size(); z++) if (hitFlag[z]) overlap.push_back(sortedTop[z]); }   // ascending
             size_t wmLimit = (size_t)std::max(0, depth - (int)overlap.size());
             size_t need = std::max<size_t>(wmLimit, 2);
             wm_first_unique(wm, sortedTop, need, uniq);
@@ -361,7 +363,7 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
             for (size_t k = 0; k < ntop && nf < 2; k++) first2[nf++] = Sq.stage1Doc[k];
             for (size_t k = 0; k < uniq.size() && nf < 2; k++) first2[nf++] = uniq[k];
             Sq.idx0 = first2[0]; Sq.idx1 = first2[1];
-            if (dbg) nsSel += since(tC);
+            if (dbg) { long long d = since(tC); nsSel += d; long long cur = nsSelMax.load(); while (d > cur && !nsSelMax.compare_exchange_weak(cur, d)) {} }
             auto tD = tick();
             covErr[i] = prepare_cov_query(ix, st, covQ[i]);
             if (dbg) nsCovQ += since(tD);
@@ -376,7 +378,7 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
             if (dbg) nsPush += since(tE);
         }
     });
-    if (dbg) fprintf(stderr, "[infx] prep2 cpu-ms: merge %.1f wm %.1f select %.1f covq %.1f push %.1f | wall %.1f\n", nsMerge / 1e6, nsWm / 1e6, nsSel / 1e6, nsCovQ / 1e6, nsPush / 1e6, now_ms() - B.t2);
+    if (dbg) fprintf(stderr, "[infx] prep2 cpu-ms: merge %.1f wm %.1f select %.1f (max %.2f) covq %.1f push %.1f | wall %.1f\n", nsMerge / 1e6, nsWm / 1e6, nsSel / 1e6, nsSelMax / 1e6, nsCovQ / 1e6, nsPush / 1e6, now_ms() - B.t2);
     for (uint32_t i = 0; i < nq; i++) if (covErr[i]) return efail(covErr[i], "query exceeds the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length)");
     std::vector<infx_cov_query> covBatch; std::vector<infx_cov_cand>& cands = S->lastCands;
     size_t ncand = 0;
@@ -503,8 +505,8 @@ static int32_t ph_finalize(infx_engine* e, infx_session* S, const infx_cov_out* 
         for (auto& P : plans) { if (P.blank || P.unsupported || P.noTerms) continue; nm[P.q.mode]++; maxT = std::max(maxT, P.terms.size());
             for (auto& t : P.terms) dfsum[P.q.mode] += t.term_id >= 0 ? (unsigned long long)ix.terms.len((uint32_t)t.term_id) : t.extra_len; }
         fprintf(stderr, "[infx] modes: prefix=%d disj=%d and=%d | postings per mode: %llu %llu %llu | maxT=%zu\n", nm[1], nm[2], nm[3], dfsum[1], dfsum[2], dfsum[3], maxT);
-        fprintf(stderr, "[infx] nq=%u dev=%u terms=%zu extra=%zu cands=%zu | plan %.1f (build %.1f) s1 %.1f prep2 %.1f s2 %.1f post %.1f ms | fuzzy calls=%lld %.1f ms-cpu (ld1 %.1f) docs=%lld\n",
-                nq, B.nd, B.dterms.size(), B.extra.size(), cands.size(), B.t1 - B.t0, B.tPlanPar, B.t2 - B.t1, B.t3 - B.t2, B.t4 - B.t3, t5 - B.t4,
+        fprintf(stderr, "[infx] nq=%u dev=%u terms=%zu extra=%zu cands=%zu | plan %.1f (tokens %.1f unions[%zu] %.1f finish %.1f) s1 %.1f prep2 %.1f s2 %.1f post %.1f ms | fuzzy calls=%lld %.1f ms-cpu (ld1 %.1f) docs=%lld\n",
+                nq, B.nd, B.dterms.size(), B.extra.size(), cands.size(), B.t1 - B.t0, B.tTok, B.pending.size(), B.tUnion - B.tTok, B.tPlanPar - B.tUnion, B.t2 - B.t1, B.t3 - B.t2, B.t4 - B.t3, t5 - B.t4,
                 (long long)e->fuzzy.fuzzyCalls.exchange(0), e->fuzzy.fuzzyNs.exchange(0) / 1e6, e->fuzzy.ld1Ns.exchange(0) / 1e6, (long long)e->fuzzy.fuzzyDocs.exchange(0));
     }
     S->tPrep1 = B.t1 - B.t0; S->tStage1 = B.t2 - B.t1; S->tPrep2 = B.t3 - B.t2; S->tStage2 = B.t4 - B.t3; S->tPost = t5 - B.t4;

@@ -364,6 +364,28 @@ inline bool wm_contains(const WmResult& R, int32_t doc) {
     for (auto& l : R.lists) if (std::binary_search(l.p, l.p + l.n, doc)) return true;
     return false;
 }
+// hit[i] |= (q[i] in list) for m probes: branch-free binary searches advanced level by level with the next level's cache line
+// prefetched, so the probes' DRAM misses overlap instead of serialising (a common word's list has ~10^5..10^6 ids)
+inline void wm_contains_batch(const WmResult& R, const int32_t* q, int m, std::vector<uint8_t>& hit, std::vector<uint32_t>& base) {
+    hit.assign(m, 0);
+    for (auto& l : R.lists) {
+        if (l.n == 0) continue;
+        if (l.n < 32 || m < 8) { for (int i = 0; i < m; i++) if (!hit[i] && std::binary_search(l.p, l.p + l.n, q[i])) hit[i] = 1; continue; }
+        base.assign(m, 0);
+        size_t len = l.n;
+        while (len > 1) {
+            const size_t half = len / 2, nlen = len - half, nhalf = nlen / 2;
+            for (int i = 0; i < m; i++) {
+                uint32_t b = base[i];
+                b += (l.p[b + half - 1] < q[i]) ? (uint32_t)half : 0u;
+                base[i] = b;
+                if (nhalf) __builtin_prefetch(l.p + b + nhalf - 1);
+            }
+            len = nlen;
+        }
+        for (int i = 0; i < m; i++) { size_t b = base[i] + (l.p[base[i]] < q[i] ? 1 : 0); if (b < l.n && l.p[b] == q[i]) hit[i] = 1; }
+    }
+}
 // first `limit` ids of the union in ascending order that are not in `exclude` (sorted)
 inline void wm_first_unique(const WmResult& R, const std::vector<int32_t>& excludeSorted, size_t limit, std::vector<int32_t>& out) {
     out.clear();

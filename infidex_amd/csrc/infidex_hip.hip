@@ -236,6 +236,10 @@ int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float
         HIPCHK(hipMemcpy(dTO, text_offs, ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dTx, text, (size_t)tot * 2, hipMemcpyHostToDevice));
     }
+    if (ix->cfg.range_docs == 0) {   // default: wide ranges for large shards (fewer, longer per-range posting slices; measured best at 10M docs)
+        int R = N >= (4u << 20) ? 8192 : N >= (1u << 20) ? 4096 : N >= (1u << 18) ? 2048 : 1024;
+        ix->d.R = R; ix->d.rshift = __builtin_ctz(R);
+    }
     ix->d.N = (int32_t)N; ix->d.docNorm = dNorm; ix->d.docKey = dKey; ix->d.textOff = dTO; ix->d.text = dTx;
     ix->d.nRanges = (int32_t)(((uint64_t)N + ix->d.R - 1) >> ix->d.rshift);
     if (ix->d.nRanges == 0) ix->d.nRanges = 1;
@@ -568,7 +572,7 @@ int32_t infx_last_timings(infx_stream* s, float* a, float* b, float* c) {
     return INFX_OK;
 }
 int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out) {
-    if (!s || (nv && (!member_offs || !members || !counts_out))) return fail(INFX_EINVAL, "null argument%s");
+    if (!s || (nv && (!member_offs || !counts_out || (member_offs[nv] && !members)))) return fail(INFX_EINVAL, "null argument%s");
     s->unionCount.clear(); s->unionBase.assign(1, 0);
     if (nv == 0) return INFX_OK;
     infx_index* ix = s->ix;
