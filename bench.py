@@ -62,8 +62,9 @@ def main():
     from infidex_amd import SearchEngine, Session, build as _build
     _build.build()
 
-    ncpu = os.cpu_count() or 8
-    bthreads = args.build_threads or max(4, min(64, ncpu // max(1, world)))
+    from infidex_amd.engine import load_library
+    ncpu = int(load_library().infx_engine_effective_cpus())     # hardware threads capped by affinity and the cgroup CPU quota
+    bthreads = args.build_threads or max(1, min(64, ncpu // max(1, world)))
     full = CONFIGS[args.config]["docs"]
     syn = Synth(args.config, docs=(None if args.docs == full else args.docs), threads=bthreads)
     k = syn.cfg["k"]

@@ -25,7 +25,7 @@ typedef struct infx_engine_config {
     int32_t device;           /* HIP device ordinal; -1 = host-only engine (indexing / planning introspection; Search fails) */
     int32_t range_docs;       /* see infx_config */
     int32_t max_depth;        /* largest Query.CoverageDepth (default 500) */
-    int32_t threads;          /* host threads for indexing / query preparation; 0 = all cores */
+    int32_t threads;          /* host threads for indexing / query preparation; 0 = infx_engine_effective_cpus() */
     int32_t enable_coverage;  /* CreateDefault: 1, CreateMinimal: 0 */
     int32_t word_matcher;     /* CreateDefault: 1 (config 400 WordMatcherSetup), CreateMinimal: 0 */
     int32_t stop_term_limit;  /* 0 = 1 250 000 */
@@ -98,6 +98,9 @@ int32_t infx_engine_prefix_pop(infx_engine* e, const uint16_t* p, int32_t len);
 int32_t infx_engine_last_stage1(infx_engine* e, uint32_t qi, int64_t* keys, float* scores, int32_t cap);
 int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* docs, float* base, float* scores, uint8_t* ties,
                                 int32_t* feat, int64_t cap);
+/* CPUs usable by this process: hardware threads capped by the affinity mask and the cgroup CPU quota (INFX_THREADS overrides);
+ * the default size of the host worker pool and of `threads`. */
+int32_t infx_engine_effective_cpus(void);
 int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uint16_t* out, int32_t cap);
 int32_t infx_engine_device_handles(infx_engine* e, infx_index** idx, infx_stream** st);
 

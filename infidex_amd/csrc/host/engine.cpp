@@ -88,7 +88,7 @@ int32_t infx_engine_create(const infx_engine_config* cfg, infx_engine** out) {
     if (cfg->stop_term_limit > 0) h.stopTermLimit = cfg->stop_term_limit;
     h.maxDepth = cfg->max_depth > 0 ? cfg->max_depth : 500;
     h.threads = cfg->threads;
-    e->threads = cfg->threads > 0 ? cfg->threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    e->threads = cfg->threads > 0 ? cfg->threads : effective_cpus();
     if (cfg->device >= 0) {
         infx_config dc{}; dc.device = cfg->device; dc.range_docs = cfg->range_docs; dc.max_depth = h.maxDepth;
         int32_t rc = infx_create(&dc, &e->dev);
@@ -701,6 +701,8 @@ int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* doc
     }
     return n;
 }
+int32_t infx_engine_effective_cpus(void) { return effective_cpus(); }
+
 int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uint16_t* out, int32_t cap) {
     ustr r = normalize(uview((const u16*)s, len)); if (lower) lower_inplace(r);
     std::memcpy(out, r.data(), (size_t)std::min<int>(cap, (int)r.size()) * 2);

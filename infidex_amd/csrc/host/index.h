@@ -20,11 +20,34 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <cstdlib>
+#include <cstdio>
+#include <sched.h>
 #include <memory>
 #include <condition_variable>
 #include <mutex>
 
 namespace infx {
+
+// CPUs this process may actually use: hardware threads, capped by the affinity mask and the cgroup CPU quota (a container with
+// cpu.max = 16 CPUs on a 256-thread host is throttled for the rest of each 100 ms period once 64 busy threads have burnt the quota —
+// measured as 40-70 ms process-wide stalls — so parallel regions are sized to the quota, not to the core count).
+inline int effective_cpus() {
+    static const int n = [] {
+        int hc = (int)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { int c = CPU_COUNT(&set); if (c > 0) hc = std::min(hc, c); }
+        auto read2 = [](const char* path, long long& a, long long& b) { FILE* f = fopen(path, "r"); if (!f) return false; char buf[64] = {0}; bool ok = false;
+            if (fgets(buf, sizeof buf, f)) { if (strncmp(buf, "max", 3) == 0) { a = -1; ok = true; } else ok = sscanf(buf, "%lld %lld", &a, &b) >= 1; } fclose(f); return ok; };
+        long long q = -1, per = 100000;
+        if (read2("/sys/fs/cgroup/cpu.max", q, per)) { /* cgroup v2 */ }
+        else { long long d = 0; if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q, d)) { long long pp = 0; if (read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", pp, d) && pp > 0) per = pp; } }
+        if (q > 0 && per > 0) hc = std::min<long long>(hc, std::max<long long>(1, (q + per - 1) / per));
+        if (const char* e = getenv("INFX_THREADS")) { int v = atoi(e); if (v > 0) hc = v; }
+        return std::max(1, hc);
+    }();
+    return n;
+}
 
 // ---- host worker pool ------------------------------------------------------------------------------------------------
 // One process-wide pool (hardware threads - 1 workers; the calling thread always takes part).  A parallel region is a shared
@@ -42,7 +65,7 @@ struct Pool {
     static Pool& get() { static Pool* p = new Pool(); return *p; }    // never destroyed: workers are detached
     static bool& in_worker() { static thread_local bool w = false; return w; }
     Pool() {
-        unsigned hc = std::thread::hardware_concurrency(); nworkers = hc > 1 ? (int)hc - 1 : 0;
+        int hc = effective_cpus(); nworkers = hc > 1 ? hc - 1 : 0;
         for (int i = 0; i < nworkers; i++) std::thread([this] { worker(); }).detach();
     }
     void worker() {
@@ -243,7 +266,7 @@ struct DocSource {   // n docs, fieldCount fields each; offs has n*fieldCount+1 
 
 inline void build_index(const DocSource& src, HostIndex& ix) {
     const HostConfig& cfg = ix.cfg;
-    int threads = cfg.threads > 0 ? cfg.threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    int threads = cfg.threads > 0 ? cfg.threads : effective_cpus();
     if (src.n < 4096) threads = 1;
     const int64_t N = src.n;
     ix.N = (int32_t)N;

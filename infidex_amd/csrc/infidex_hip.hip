@@ -14,6 +14,7 @@
 // (quirk Q11) are evaluated from per-doc flags; a range that holds no candidate-generating posting exits before it
 // streams anything else (range-granular WAND skip). Survivors are compacted with wave ballots into a batch arena and
 // k_select picks the top-`depth` per query with an LDS radix select + bitonic sort.
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -139,6 +140,8 @@ struct infx_stream {
     void* dQBytes = nullptr; size_t capQBytes = 0;
     void* dUOffs = nullptr; size_t capUOffs = 0; void* dUMem = nullptr; size_t capUMem = 0; void* dUCnt = nullptr; size_t capUCnt = 0;
     void* dURange = nullptr; size_t capURange = 0; void* dUBase = nullptr; size_t capUBase = 0; void* dUDocs = nullptr; size_t capUDocs = 0;
+    struct PinChunk { char* base; size_t cap, off; }; std::vector<PinChunk> pins;      // pinned staging arena
+    struct PendingOut { void* dst; const void* src; size_t bytes; }; std::vector<PendingOut> pendingOut; bool unsynced = false;
     std::vector<uint32_t> unionCount; std::vector<unsigned long long> unionBase{0};   // device-resident unions of the last infx_union_build
     void* dCounts = nullptr; size_t capCounts = 0;
     void* dCovQ = nullptr; size_t capCovQ = 0;
@@ -163,6 +166,49 @@ static int32_t grow(void** p, size_t* cap, size_t need) {
     *cap = n; return INFX_OK;
 }
 #define GROW(p, cap, need) do { int32_t rc_ = grow((void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)
+
+// ---- host <-> device transfers through pinned staging -------------------------------------------------------------------
+// The C ABI takes plain (pageable) host pointers.  Handing those to hipMemcpyAsync makes the runtime pin/unpin the caller's pages
+// per copy, which takes the process-wide address-space lock and stalls every host thread that page-faults meanwhile (observed:
+// 50-70 ms stalls of unrelated planning threads with three sessions in flight).  Each stream therefore owns a pinned arena:
+// inputs are copied into it and DMA'd from there; outputs are DMA'd into it and copied out after the stream synchronises.
+static void* pin_take(infx_stream* s, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (auto& c : s->pins) if (c.cap - c.off >= bytes) { void* p = c.base + c.off; c.off += bytes; return p; }
+    size_t cap = std::max<size_t>(bytes, s->pins.empty() ? (size_t)8 << 20 : s->pins.back().cap * 2);
+    void* b = nullptr;
+    if (hipHostMalloc(&b, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    s->pins.push_back({(char*)b, cap, bytes});
+    return b;
+}
+static int32_t stream_sync(infx_stream* s) {
+    HIPCHK(hipStreamSynchronize(s->st));
+    for (auto& d : s->pendingOut) std::memcpy(d.dst, d.src, d.bytes);
+    s->pendingOut.clear(); s->unsynced = false;
+    return INFX_OK;
+}
+static int32_t pin_reset(infx_stream* s) {     // start of an API call: the staging of the previous call must have been consumed
+    if (s->unsynced) { int32_t rc = stream_sync(s); if (rc) return rc; }
+    for (auto& c : s->pins) c.off = 0;
+    return INFX_OK;
+}
+static int32_t up(infx_stream* s, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return INFX_OK;
+    void* p = pin_take(s, bytes); if (!p) return fail(INFX_ENOMEM, "hipHostMalloc staging failed%s");
+    std::memcpy(p, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, s->st)); s->unsynced = true;
+    return INFX_OK;
+}
+static int32_t down(infx_stream* s, void* dstHost, const void* srcDev, size_t bytes) {   // lands in dstHost at the next stream_sync
+    if (!bytes) return INFX_OK;
+    void* p = pin_take(s, bytes); if (!p) return fail(INFX_ENOMEM, "hipHostMalloc staging failed%s");
+    HIPCHK(hipMemcpyAsync(p, srcDev, bytes, hipMemcpyDeviceToHost, s->st)); s->unsynced = true;
+    s->pendingOut.push_back({dstHost, p, bytes});
+    return INFX_OK;
+}
+#define UP(dst, src, n) do { int32_t rc_ = up(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
+#define DOWN(dst, src, n) do { int32_t rc_ = down(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
+#define SYNC() do { int32_t rc_ = stream_sync(s); if (rc_) return rc_; } while (0)
 
 template <int R> static void launch_union(infx_stream* s, uint32_t nv, const uint32_t* dOffs, const int32_t* dMembers, uint32_t* dRangeCount,
                                             const unsigned long long* dBase, int32_t* outDocs) {
@@ -319,6 +365,8 @@ void infx_stream_destroy(infx_stream* s) {
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow};
     for (void* p : ps) if (p) hipFree(p);
+    if (s->st) hipStreamSynchronize(s->st);
+    for (auto& c : s->pins) hipHostFree(c.base);
     hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1};
     for (auto e : ev) hipEventDestroy(e);
     if (s->st) hipStreamDestroy(s->st);
@@ -332,6 +380,7 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
     if (nq == 0) return INFX_OK;
     HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     if ((uint64_t)nq * ix->d.nRanges > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nq * nRanges exceeds the grid limit; split the batch%s");
     // translate + capacity bound.  A virtual term given as a MEMBER LIST (infx_term.reserved == 1: extra_docs[extra_off..+len) are index
     // term ids) is expanded into one device entry per member, all sharing the term's idf / role / rank and a dedupe group.
@@ -420,10 +469,10 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     }
     for (size_t i = 0; i < dt.size(); i++) if (termOfEntry[i] >= 0) dt[i].skip = (*skipMirror)[termOfEntry[i]];
 
-    HIPCHK(hipMemcpyAsync(s->dQueries, dq.data(), nq * sizeof(DevQuery), hipMemcpyHostToDevice, s->st));
-    if (!dt.empty()) HIPCHK(hipMemcpyAsync(s->dTerms, dt.data(), dt.size() * sizeof(DevTerm), hipMemcpyHostToDevice, s->st));
-    if (extra_n) HIPCHK(hipMemcpyAsync(s->dExtra, extra_docs, (size_t)extra_n * 4, hipMemcpyHostToDevice, s->st));
-    HIPCHK(hipMemcpyAsync(s->dBlockOut, qbase.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, s->st));
+    UP(s->dQueries, dq.data(), nq * sizeof(DevQuery));
+    UP(s->dTerms, dt.data(), dt.size() * sizeof(DevTerm));
+    UP(s->dExtra, extra_docs, (size_t)extra_n * 4);
+    UP(s->dBlockOut, qbase.data(), ((size_t)nq + 1) * 8);
     HIPCHK(hipMemsetAsync(s->dQBytes, 0, (size_t)nq * 8, s->st));
     HIPCHK(hipMemsetAsync(s->dOverflow, 0, 4, s->st));
     HIPCHK(hipMemsetAsync(s->dCounts, 0, (size_t)nq * INFX_NCLASS * 4, s->st));
@@ -443,10 +492,10 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     HIPCHK(hipEventRecord(s->evA1, s->st));
     s->timedAcc = true;
     uint32_t ovf = 0; std::vector<unsigned long long> qbytes(nq);
-    if (counts_out) HIPCHK(hipMemcpyAsync(counts_out, s->dCounts, (size_t)nq * INFX_NCLASS * 4, hipMemcpyDeviceToHost, s->st));
-    HIPCHK(hipMemcpyAsync(&ovf, s->dOverflow, 4, hipMemcpyDeviceToHost, s->st));
-    HIPCHK(hipMemcpyAsync(qbytes.data(), s->dQBytes, (size_t)nq * 8, hipMemcpyDeviceToHost, s->st));
-    HIPCHK(hipStreamSynchronize(s->st));
+    if (counts_out) DOWN(counts_out, s->dCounts, (size_t)nq * INFX_NCLASS * 4);
+    DOWN(&ovf, s->dOverflow, 4);
+    DOWN(qbytes.data(), s->dQBytes, (size_t)nq * 8);
+    SYNC();
     if (ovf) return fail(INFX_ECAPACITY, "candidate arena overflow (bound violated)%s");
     s->lastAlgBytes = 0; for (auto b : qbytes) s->lastAlgBytes += b;
     s->lastQ.assign(q, q + nq); s->lastNq = nq;
@@ -503,6 +552,7 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     if (nq != s->lastNq) return fail(INFX_EINVAL, "infx_stage1_select must follow infx_stage1_accumulate of the same batch%s");
     infx_index* ix = s->ix;
     HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     std::vector<SelRule> rules(nq);
     int maxDepth = 0;
     s->lastCandTotal = 0;
@@ -510,7 +560,7 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     GROW(s->dRules, s->capRules, nq * sizeof(SelRule));
     GROW(s->dHits, s->capHits, (size_t)nq * maxDepth * sizeof(infx_hit));
     GROW(s->dHitCount, s->capHitCount, (size_t)nq * 4);
-    HIPCHK(hipMemcpyAsync(s->dRules, rules.data(), nq * sizeof(SelRule), hipMemcpyHostToDevice, s->st));
+    UP(s->dRules, rules.data(), nq * sizeof(SelRule));
     Arena ar{s->arDoc, s->arScore, s->arCls, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
              (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes};
     HIPCHK(hipEventRecord(s->evS0, s->st));
@@ -519,9 +569,9 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     HIPCHK(hipEventRecord(s->evS1, s->st));
     s->timedSel = true;
     std::vector<infx_hit> tmp((size_t)nq * maxDepth);
-    HIPCHK(hipMemcpyAsync(tmp.data(), s->dHits, tmp.size() * sizeof(infx_hit), hipMemcpyDeviceToHost, s->st));
-    HIPCHK(hipMemcpyAsync(out_count, s->dHitCount, (size_t)nq * 4, hipMemcpyDeviceToHost, s->st));
-    HIPCHK(hipStreamSynchronize(s->st));
+    DOWN(tmp.data(), s->dHits, tmp.size() * sizeof(infx_hit));
+    DOWN(out_count, s->dHitCount, (size_t)nq * 4);
+    SYNC();
     // caller layout: nq * depth_i packed with the query's own depth as stride == we use max depth of the batch as stride
     for (uint32_t i = 0; i < nq; i++) memcpy(out + (size_t)i * maxDepth, tmp.data() + (size_t)i * maxDepth, (size_t)out_count[i] * sizeof(infx_hit));
     return INFX_OK;
@@ -542,6 +592,7 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     infx_index* ix = s->ix;
     if (!ix->haveDocs || !ix->d.text) return fail(INFX_EINVAL, "document text not uploaded%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     for (uint32_t i = 0; i < nq; i++)
         if (q[i].num_tokens > INFX_MAX_QUERY_TOKENS || q[i].text_len > INFX_MAX_QUERY_CHARS || q[i].num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS)
             return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope%s");
@@ -549,17 +600,17 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     GROW(s->dCovC, s->capCovC, (size_t)ncand * sizeof(infx_cov_cand));
     GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
     if (feat_out) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
-    HIPCHK(hipMemcpyAsync(s->dCovQ, q, (size_t)nq * sizeof(infx_cov_query), hipMemcpyHostToDevice, s->st));
-    HIPCHK(hipMemcpyAsync(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand), hipMemcpyHostToDevice, s->st));
+    UP(s->dCovQ, q, (size_t)nq * sizeof(infx_cov_query));
+    UP(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand));
     HIPCHK(hipEventRecord(s->evC0, s->st));
     k_stage2<<<(ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st>>>(ix->d, (const infx_cov_query*)s->dCovQ, nq,
                                                                                  (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
     s->timedCov = true;
-    HIPCHK(hipMemcpyAsync(out, s->dCovO, (size_t)ncand * sizeof(infx_cov_out), hipMemcpyDeviceToHost, s->st));
-    if (feat_out) HIPCHK(hipMemcpyAsync(feat_out, s->dCovF, (size_t)ncand * INFX_NFEAT * 4, hipMemcpyDeviceToHost, s->st));
-    HIPCHK(hipStreamSynchronize(s->st));
+    DOWN(out, s->dCovO, (size_t)ncand * sizeof(infx_cov_out));
+    if (feat_out) DOWN(feat_out, s->dCovF, (size_t)ncand * INFX_NFEAT * 4);
+    SYNC();
     return INFX_OK;
 }
 
@@ -578,6 +629,7 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     infx_index* ix = s->ix;
     if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     const int nR = ix->d.nRanges;
     if ((uint64_t)nv * nR > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nv * nRanges exceeds the grid limit%s");
     const uint32_t nm = member_offs[nv];
@@ -587,18 +639,18 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     GROW(s->dUCnt, s->capUCnt, (size_t)nv * 4);
     GROW(s->dURange, s->capURange, (size_t)nv * (nR + 1) * 4);
     GROW(s->dUBase, s->capUBase, ((size_t)nv + 1) * 8);
-    HIPCHK(hipMemcpyAsync(s->dUOffs, member_offs, ((size_t)nv + 1) * 4, hipMemcpyHostToDevice, s->st));
-    if (nm) HIPCHK(hipMemcpyAsync(s->dUMem, members, (size_t)nm * 4, hipMemcpyHostToDevice, s->st));
+    UP(s->dUOffs, member_offs, ((size_t)nv + 1) * 4);
+    UP(s->dUMem, members, (size_t)nm * 4);
     launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, nullptr, nullptr);
     k_union_scan<<<nv, 256, 0, s->st>>>((uint32_t*)s->dURange, nR, (uint32_t*)s->dUCnt);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(counts_out, s->dUCnt, (size_t)nv * 4, hipMemcpyDeviceToHost, s->st));
-    HIPCHK(hipStreamSynchronize(s->st));
+    DOWN(counts_out, s->dUCnt, (size_t)nv * 4);
+    SYNC();
     s->unionCount.assign(counts_out, counts_out + nv);
     s->unionBase.assign((size_t)nv + 1, 0);
     for (uint32_t v = 0; v < nv; v++) s->unionBase[v + 1] = s->unionBase[v] + counts_out[v];
     GROW(s->dUDocs, s->capUDocs, std::max<size_t>(1, s->unionBase[nv]) * 4);
-    HIPCHK(hipMemcpyAsync(s->dUBase, s->unionBase.data(), ((size_t)nv + 1) * 8, hipMemcpyHostToDevice, s->st));
+    UP(s->dUBase, s->unionBase.data(), ((size_t)nv + 1) * 8);
     launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, (const unsigned long long*)s->dUBase, (int32_t*)s->dUDocs);
     HIPCHK(hipGetLastError());
     return INFX_OK;     // the write pass stays queued on the stream; infx_stage1_accumulate is ordered behind it
