@@ -178,6 +178,52 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------ */
 /* Durations (ms) of the last Stage-1 accumulate / select / Stage-2 launches on this stream, from HIP events recorded on
  * the stream the kernels ran on. */
+/* ---- Whole batch on the device (unsharded index) -----------------------------------------------------------------
+ * infx_search_fused runs SearchEngine.Search for a batch with ONE host synchronisation: accumulate -> tier rules -> select ->
+ * coverage-stage candidate assembly (SearchPipeline.ExecuteCoverageStage, SearchPipeline.cs:330-420, incl. the WordMatcher
+ * overlap / first-unique lookups of WordMatcher.Lookup, WordMatcher.cs:95-186) -> Stage 2 -> TopKHeap + ConsolidateSegments +
+ * CalculateTruncationIndex (SearchPipeline.cs:422-560); only max_results rows per query return to the host.
+ * The host supplies what needs the dictionaries: query terms / idf / roles (as for infx_stage1_accumulate), the prepared
+ * coverage query, and per query the WordMatcher doc-id lists as ranges of the uploaded arrays. */
+int32_t infx_upload_wordmatcher(infx_index* idx, uint64_t n_exact, const int32_t* exact_docs, uint64_t n_ld1, const int32_t* ld1_docs);
+
+typedef struct infx_wm_list {      /* one ascending doc-id list */
+    uint32_t src;                  /* 0: exact_docs, 1: ld1_docs (infx_upload_wordmatcher), 2: the call's `owned` buffer (affix matches) */
+    uint32_t len;
+    uint64_t off;
+} infx_wm_list;
+
+#define INFX_FQ_SKIP 1u            /* blank / unsupported query text: empty result */
+#define INFX_FQ_SHORT 2u           /* 1..3 characters without delimiter (SearchPipeline.cs:108-120) */
+#define INFX_FQ_SHORTSKIP 4u       /* short query whose prefix population exceeds 500: coverage is skipped */
+#define INFX_FQ_COV 8u             /* coverage enabled (engine setup && Query.EnableCoverage) */
+#define INFX_FQ_UNSUPPORTED 16u    /* result flag bit0 is set */
+#define INFX_MAX_WM_LISTS 256
+typedef struct infx_fused_query {
+    int32_t  dev;                  /* index into q[] of the Stage-1 part, or -1 (no index term) */
+    uint32_t flags;                /* INFX_FQ_* */
+    uint32_t wm_off, wm_count;     /* lists[wm_off .. +wm_count), non-empty lists only, <= INFX_MAX_WM_LISTS */
+    int32_t  max_results;          /* Query.MaxNumberOfRecordsToReturn */
+    int32_t  reserved;
+} infx_fused_query;
+
+/* nd Stage-1 queries q[] (+ terms), nq search queries fq[]/cq[] (nq >= nd; cq[i] is ignored unless coverage runs for i).
+ * All queries must share one depth.  out_*: nq x max_results rows; out_flags bits as infx_engine_search_batch. */
+int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint32_t nterms, const infx_term* terms,
+                          uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq,
+                          uint32_t nlists, const infx_wm_list* lists, uint32_t owned_n, const int32_t* owned,
+                          int32_t depth, int32_t max_results, int32_t want_debug,
+                          int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags);
+/* After an infx_search_fused call with want_debug != 0: the intermediate device results (parity tests / introspection).
+ * s1: nq x depth (ConsolidateSegments order) + counts; cands/outs/feat: nq x 2*depth rows, cand_counts[i] of them valid;
+ * idx01: nq x 2 (documents with docIndex 0 / 1, -1 if absent).  Any pointer may be NULL. */
+int32_t infx_fused_debug(infx_stream* s, infx_hit* s1, uint32_t* s1_counts, infx_cov_cand* cands, infx_cov_out* outs, int32_t* feat,
+                         uint32_t* cand_counts, uint32_t* run_cov, int32_t* idx01);
+/* kernel durations of the last fused call: accumulate, rules+select, prep2, stage2, finalize */
+int32_t infx_last_fused_timings(infx_stream* s, float* ms5);
+/* totals of the last fused call: Stage-1 rows kept, Stage-2 candidate rows scored, UTF-16 bytes of their texts */
+int32_t infx_last_fused_stats(infx_stream* s, uint64_t* s1_rows, uint64_t* stage2_rows, uint64_t* stage2_text_bytes);
+
 int32_t infx_last_timings(infx_stream* s, float* accumulate_ms, float* select_ms, float* stage2_ms);
 /* Bytes the last accumulate launch actually streamed (posting slices of the doc ranges that held candidates: 5 B/posting,
  * 4 B for virtual terms, + 12 B per emitted arena entry) — an implementation figure, <= the algorithmic bytes of SURVEY 8(d). */

@@ -52,7 +52,7 @@ struct infx_session {
     Batch* batch = nullptr;
     infx_stream* stream = nullptr;
     double tPrep1 = 0, tStage1 = 0, tPrep2 = 0, tStage2 = 0, tPost = 0;
-    float msAcc = 0, msSel = 0, msCov = 0; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0;
+    float msAcc = 0, msSel = 0, msCov = 0, msPrep2 = 0, msFin = 0; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0;
     // last-batch introspection for parity tests
     std::vector<QueryPlan> lastPlans;
     std::vector<infx_hit> lastHits; std::vector<uint32_t> lastHitCount; int lastStride = 0;
@@ -130,6 +130,7 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
             rc = infx_upload_docs(e->dev, (uint32_t)ix.N, ix.docLen.data(), ix.avgdl, ix.docKey.data(), ix.textOff.data(), (const uint16_t*)ix.text.data());
             if (!rc) rc = infx_upload_postings(e->dev, (uint32_t)ix.terms.K(), ix.terms.off.data(), ix.terms.doc.data(), ix.terms.w.data(), ix.df.data());
             if (!rc) rc = infx_upload_prefix_docsets(e->dev, (uint32_t)(ix.psOff.size() - 1), ix.psOff.data(), ix.psDocs.data());
+            if (!rc && ix.cfg.wordMatcher) rc = infx_upload_wordmatcher(e->dev, ix.wmExact.doc.size(), ix.wmExact.doc.data(), ix.wmLd1.doc.size(), ix.wmLd1.doc.data());
         } else {
             // global statistics (df, avgdl, N, prefix populations, word IDF) stay on the host; the GPU gets this shard's slices, rebased
             const int32_t sb = e->shardBase, sn = e->shardN, se = sb + sn;
@@ -513,12 +514,110 @@ static int32_t ph_finalize(infx_engine* e, infx_session* S, const infx_cov_out* 
     return INFX_OK;
 }
 
+// Unsharded engines: the whole batch on the device with one synchronisation (infx_search_fused).  The host keeps what needs
+// its dictionaries: text preparation, term lookup, LD1 expansion, idf / roles (ph_plan*), and per query the WordMatcher list
+// descriptors (WordMatcher.Lookup, WordMatcher.cs:95-186) + CoverageEngine.PrepareQuery.
+static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
+                                  int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
+                                  uint32_t* out_counts, uint32_t* out_flags) {
+    int32_t rc = ph_plan(e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
+    rc = ph_plan_finish(e, S, S->batch->pendingCounts.data()); if (rc) return rc;
+    Batch& B = *S->batch; const HostIndex& ix = e->ix; const int threads = e->threads;
+    std::vector<QueryPlan>& plans = S->lastPlans;
+    const bool covEnabled = ix.cfg.enableCoverage && enable_coverage;
+    std::vector<infx_fused_query> fq(nq); std::vector<infx_cov_query> cq(nq);
+    std::vector<std::vector<infx_wm_list>> qLists(nq); std::vector<std::vector<int32_t>> qOwned(nq);
+    std::vector<int32_t> covErr(nq, 0);
+    const int32_t* exB = ix.wmExact.doc.data(); const int32_t* exE = exB + ix.wmExact.doc.size();
+    const int32_t* l1B = ix.wmLd1.doc.data(); const int32_t* l1E = l1B + ix.wmLd1.doc.size();
+    parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
+        WmResult wm;
+        for (int64_t i = b; i < en; i++) {
+            const QueryPlan& P = plans[i]; infx_fused_query& F = fq[i];
+            F = infx_fused_query{}; F.dev = -1; F.max_results = max_results;
+            if (P.blank || P.unsupported) { F.flags = INFX_FQ_SKIP | (P.unsupported ? INFX_FQ_UNSUPPORTED : 0u); continue; }
+            F.dev = B.devOf[i];
+            const ustr& st = P.searchText;
+            bool isShort = !st.empty() && st.size() <= 3;
+            if (isShort) for (u16 ch : st) if (is_delim(ch)) { isShort = false; break; }
+            if (isShort) { F.flags |= INFX_FQ_SHORT; int64_t pk = ix.prefixKeys.find(st); int shortCount = pk >= 0 ? (int)ix.prefixPop[pk] : 0; if (shortCount > 500) F.flags |= INFX_FQ_SHORTSKIP; }
+            if (!covEnabled || (F.flags & INFX_FQ_SHORTSKIP)) continue;
+            F.flags |= INFX_FQ_COV;
+            wm_collect(ix, st, true, wm);
+            for (auto& l : wm.lists) {
+                if (!l.n) continue;
+                infx_wm_list L{}; L.len = (uint32_t)l.n;
+                if (l.p >= exB && l.p < exE) { L.src = 0; L.off = (uint64_t)(l.p - exB); }
+                else if (l.p >= l1B && l.p < l1E) { L.src = 1; L.off = (uint64_t)(l.p - l1B); }
+                else { L.src = 2; L.off = qOwned[i].size(); qOwned[i].insert(qOwned[i].end(), l.p, l.p + l.n); }
+                qLists[i].push_back(L);
+            }
+            covErr[i] = prepare_cov_query(ix, st, cq[i]);
+        }
+    });
+    for (uint32_t i = 0; i < nq; i++) if (covErr[i]) return efail(covErr[i], "query exceeds the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length)");
+    std::vector<infx_wm_list> lists; std::vector<int32_t> owned;
+    for (uint32_t i = 0; i < nq; i++) {
+        fq[i].wm_off = (uint32_t)lists.size(); fq[i].wm_count = (uint32_t)qLists[i].size();
+        if (qLists[i].size() > INFX_MAX_WM_LISTS) return efail(INFX_ECAPACITY, "a query needs more than INFX_MAX_WM_LISTS WordMatcher lists");
+        for (auto L : qLists[i]) { if (L.src == 2) L.off += owned.size(); lists.push_back(L); }
+        owned.insert(owned.end(), qOwned[i].begin(), qOwned[i].end());
+    }
+    if (owned.size() > 0xFFFFFFF0ull) return efail(INFX_ECAPACITY, "affix matches of this batch exceed 2^32 ids; split the batch");
+    B.t2 = now_ms();
+    const bool dbg = e->cfg.want_features != 0;
+    rc = infx_search_fused(S->stream, B.nd, B.dq.data(), (uint32_t)B.dterms.size(), B.dterms.data(), nq, fq.data(), cq.data(),
+                           (uint32_t)lists.size(), lists.data(), (uint32_t)owned.size(), owned.data(), depth, max_results, dbg ? 1 : 0,
+                           out_keys, out_scores, out_ties, out_counts, out_flags);
+    if (rc) { g_eerr = infx_last_error(); return rc; }
+    B.t3 = now_ms();
+    float ms5[5] = {0, 0, 0, 0, 0}; infx_last_fused_timings(S->stream, ms5);
+    S->msAcc = ms5[0]; S->msSel = ms5[1]; S->msPrep2 = ms5[2]; S->msCov = ms5[3]; S->msFin = ms5[4];
+    uint64_t s1rows = 0; infx_last_fused_stats(S->stream, &s1rows, &S->s2Candidates, &S->s2TextBytes);
+    infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates);
+    {   // B_alg(q) = sum_t df_t * 5 B (4 B for fuzzy virtual terms) + card(C_q) * 4 B + depth * 12 B
+        uint64_t ab = 0;
+        for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
+        S->algBytes = B.nd ? ab + S->s1Candidates * 4ull + s1rows * 12ull : 0;
+    }
+    if (dbg) {   // parity tests: pull the intermediate device tables into the session's introspection buffers
+        const size_t stride = 2 * (size_t)depth;
+        std::vector<infx_hit> s1((size_t)nq * depth); std::vector<uint32_t> s1c(nq), cc(nq), rcv(nq);
+        std::vector<infx_cov_cand> cands(nq * stride); std::vector<infx_cov_out> outs(nq * stride); std::vector<int32_t> feat(nq * stride * INFX_NFEAT);
+        rc = infx_fused_debug(S->stream, s1.data(), s1c.data(), cands.data(), outs.data(), feat.data(), cc.data(), rcv.data(), nullptr);
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+        S->lastHits.assign((size_t)B.nd * depth, infx_hit{0, 0.f}); S->lastHitCount.assign(B.nd, 0); S->lastStride = depth;
+        S->lastCands.clear(); S->lastOuts.clear(); S->lastFeat.clear();
+        uint32_t covIndex = 0;
+        for (uint32_t i = 0; i < nq; i++) {
+            const int j = B.devOf.empty() ? -1 : B.devOf[i];
+            if (j >= 0) { S->lastHitCount[j] = s1c[i]; std::memcpy(S->lastHits.data() + (size_t)j * depth, s1.data() + (size_t)i * depth, (size_t)s1c[i] * sizeof(infx_hit)); }
+            if (!(rcv[i] & 1)) continue;
+            for (uint32_t k = 0; k < cc[i]; k++) {
+                infx_cov_cand c = cands[i * stride + k]; c.query = covIndex;
+                S->lastCands.push_back(c); S->lastOuts.push_back(outs[i * stride + k]);
+                S->lastFeat.insert(S->lastFeat.end(), feat.begin() + (i * stride + k) * INFX_NFEAT, feat.begin() + (i * stride + k + 1) * INFX_NFEAT);
+            }
+            covIndex++;
+        }
+    }
+    double t5 = now_ms();
+    if (getenv("INFX_DEBUG"))
+        fprintf(stderr, "[infx] fused nq=%u dev=%u terms=%zu lists=%zu owned=%zu cands=%llu | plan %.1f (tokens %.1f unions[%zu] %.1f finish %.1f) wm-prep %.1f gpu %.1f (acc %.2f sel %.2f prep2 %.2f s2 %.2f fin %.2f) post %.1f ms | fuzzy calls=%lld %.1f ms-cpu\n",
+                nq, B.nd, B.dterms.size(), lists.size(), owned.size(), (unsigned long long)S->s2Candidates, B.t1 - B.t0, B.tTok, B.pending.size(), B.tUnion - B.tTok, B.tPlanPar - B.tUnion,
+                B.t2 - B.t1, B.t3 - B.t2, ms5[0], ms5[1], ms5[2], ms5[3], ms5[4], t5 - B.t3, (long long)e->fuzzy.fuzzyCalls.exchange(0), e->fuzzy.fuzzyNs.exchange(0) / 1e6);
+    S->tPrep1 = B.t1 - B.t0; S->tStage1 = 0; S->tPrep2 = B.t2 - B.t1; S->tStage2 = B.t3 - B.t2; S->tPost = t5 - B.t3;
+    return INFX_OK;
+}
+
 static int32_t search_batch_impl(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
                                  int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                  uint32_t* out_counts, uint32_t* out_flags) {
     if (!e || (nq && (!q_arena || !q_offs || !out_keys || !out_scores || !out_counts)) || max_results < 1) return efail(INFX_EINVAL, "bad arguments");
     if (!e->indexed) { for (uint32_t i = 0; i < nq; i++) out_counts[i] = 0; return INFX_OK; }   // Result.MakeEmptyResult(), SearchEngine.cs:261-262
     if (e->nranks > 1) return efail(INFX_EINVAL, "sharded engine: drive the phase API (infx_session_phase1..4) with the collectives in between");
+    static const bool phased = getenv("INFX_PHASED") != nullptr;     // host-driven phases (the sharded code path) on one GPU
+    if (!phased) return search_batch_fused(e, S, nq, q_arena, q_offs, max_results, depth, enable_coverage, out_keys, out_scores, out_ties, out_counts, out_flags);
     int32_t rc = ph_plan(e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
     rc = ph_plan_finish(e, S, S->batch->pendingCounts.data()); if (rc) return rc;
     rc = ph_accumulate(e, S); if (rc) return rc;

@@ -42,6 +42,10 @@ struct DevIndex {
     const uint64_t* textOff; const uint16_t* text;
     const uint32_t* skipIdx;   // per term: first entry in skipTbl, or 0xFFFFFFFF
     const uint32_t* skipTbl;   // nRanges+1 offsets (relative to postOff[t]) per skipped term
+    const uint32_t* psSkip;    // per prefix DocSet: first entry in psSkipTbl, or 0xFFFFFFFF
+    const uint32_t* psSkipTbl; // nRanges+1 offsets (relative to psOff[k]) per skipped set
+    const int32_t* wmExact;    // WordMatcher exact-word doc lists (infx_upload_wordmatcher), global ids
+    const int32_t* wmLd1;      // WordMatcher symmetric-delete doc lists
     const uint64_t* psOff; const int32_t* psDocs; uint32_t nSets;
 };
 
@@ -49,7 +53,8 @@ struct infx_index {
     infx_config cfg;
     DevIndex d{};
     std::vector<void*> allocs;
-    bool havePostings = false, haveDocs = false;
+    bool havePostings = false, haveDocs = false, haveWm = false;
+    uint64_t nWmExact = 0, nWmLd1 = 0;
     float avgdl = 0.f;
     std::vector<uint64_t> hPostOff;   // host copy for capacity bounds / alg-bytes accounting
     std::vector<int32_t> hDf;
@@ -123,11 +128,62 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 #include "stage1.hip.inc"
 #include "stage2.hip.inc"
 
+// TieredCandidateSelector tier rules evaluated from class counts (see header of this file / DESIGN.md)
+__host__ __device__ static inline SelRule make_rule0(const infx_query& Q, const uint32_t* c) {
+    SelRule r{}; r.mode = Q.mode; r.depth = Q.depth; r.cutoffRank = 127; r.classMask = 0xFFFFFFFFu;
+    const long k = Q.depth;
+    if (Q.mode == INFX_MODE_AND) {
+        unsigned long long t0 = 0, t1 = 0;
+        for (int i = 0; i < 16; i++) { if (i & 1) t0 += c[i]; if (i & 2) t1 += c[i]; }
+        if ((long)t0 >= k * 2) { r.classMask = 1; return r; }                       // Tier 0 alone (:160-161)
+        unsigned long long g = t0; uint32_t gmask = 1;
+        if (Q.n_and >= 3 && (long)t0 < k * 3) { g = t1; gmask = 2 | 1; }            // Tier 1 (:165-171); T1 contains T0
+        if ((long)g < k * 5) {                                                      // Tier 2 (:174-234)
+            if (Q.df_s1 <= 0) { r.classMask = gmask; return r; }
+            if ((long)Q.df_s1 >= k * 10 || Q.df_s2 <= 0) { r.classMask = 4 | gmask; return r; }   // G u S1 == S1
+            r.classMask = 4 | 8 | gmask; return r;
+        }
+        r.classMask = gmask; return r;
+    }
+    if (Q.mode == INFX_MODE_DISJ) {
+        // SelectCandidatesDisjunctive (:260-319): ranks [0, n_and) are not low-quality, the rest are
+        int nElig = Q.n_and; bool hasSel = false; long local = 0; int cutoff = -1;
+        int nRanks = 0; for (int i = 127; i >= 0; i--) if (c[i]) { nRanks = i + 1; break; }
+        int totalRanks = nRanks > Q.df_s1 ? nRanks : Q.df_s1;   // df_s1 carries the number of ranks in DISJ mode
+        for (int i = 0; i < totalRanks; i++) {
+            bool lowq = i >= nElig;
+            if (totalRanks > 1 && lowq && hasSel) continue;
+            cutoff = i; local += c[i];
+            if (!lowq && local > 0) hasSel = true;
+            if (local >= k * 100) break;
+        }
+        r.cutoffRank = cutoff; return r;
+    }
+    return r;
+}
+
+__host__ __device__ static inline SelRule make_rule(const infx_query& Q, const uint32_t* c) {
+    SelRule r = make_rule0(Q, c);
+    unsigned long long tot = 0;
+    if (Q.mode == INFX_MODE_AND) { for (int i = 0; i < 16; i++) if (i & r.classMask) tot += c[i]; }
+    else if (Q.mode == INFX_MODE_DISJ) { for (int i = 0; i <= r.cutoffRank && i < 128; i++) tot += c[i]; tot += 128; /* pre-seen docs (< 100) are not in the histogram */ }
+    else tot = c[1];
+    r.total = (uint32_t)(tot < 0xFFFFFFFFull ? tot : 0xFFFFFFFFull); r.pad = 0;
+    return r;
+}
+
+#include "fused.hip.inc"
+
 // ---------------------------------------------------------------------------------------------------------------
 struct infx_stream {
     infx_index* ix;
     hipStream_t st = nullptr;
-    hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1;
+    hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1;
+    // fused pipeline workspaces
+    void *dFQ = nullptr, *dFLists = nullptr, *dFOwned = nullptr, *dFS1 = nullptr, *dFMeta = nullptr, *dFQueries = nullptr, *dFKeys = nullptr, *dFScores = nullptr, *dFTies = nullptr, *dFCounts = nullptr, *dFFlags = nullptr, *dFErr = nullptr;
+    size_t capFQ = 0, capFLists = 0, capFOwned = 0, capFS1 = 0, capFMeta = 0, capFQueries = 0, capFKeys = 0, capFScores = 0, capFTies = 0, capFCounts = 0, capFFlags = 0, capFErr = 0;
+    uint64_t fusedS1 = 0, fusedCands = 0, fusedTextBytes = 0;
+    uint32_t fusedNq = 0; int fusedDepth = 0; bool fusedDebug = false, timedFused = false; float msFused[5] = {0, 0, 0, 0, 0};
     // device workspaces (grown on demand)
     void* dQueries = nullptr; size_t capQueries = 0;
     void* dTerms = nullptr; size_t capTerms = 0;
@@ -227,10 +283,10 @@ static void launch_union_any(infx_stream* s, uint32_t nv, const uint32_t* dOffs,
     }
 }
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT) {
-    size_t lds = (size_t)(R / 32) * 8 + (size_t)ACC_CAP * 9 + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
+    size_t lds = (size_t)(R / 32) * 8 + 8 + (size_t)ACC_CAP * 13 + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
     uint64_t blocks = (uint64_t)nq * s->ix->d.nRanges;
     k_accumulate<R><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, nq, ar, maxT);
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT);
 }
 
 extern "C" {
@@ -300,17 +356,25 @@ int32_t infx_upload_postings(infx_index* ix, uint32_t T, const uint64_t* offs, c
     HIPCHK(hipSetDevice(ix->cfg.device));
     uint64_t P = offs[T];
     uint64_t* dOff = nullptr; int32_t* dDoc = nullptr; uint8_t* dW = nullptr;
-    HIPCHK(dalloc(ix, &dOff, (size_t)T + 1)); HIPCHK(dalloc(ix, &dDoc, (size_t)P)); HIPCHK(dalloc(ix, &dW, (size_t)P));
+    HIPCHK(dalloc(ix, &dOff, (size_t)T + 1)); HIPCHK(dalloc(ix, &dDoc, (size_t)P + 4)); HIPCHK(dalloc(ix, &dW, (size_t)P));   // +4: k_accumulate reads whole 16-byte groups
     HIPCHK(hipMemcpy(dOff, offs, ((size_t)T + 1) * 8, hipMemcpyHostToDevice));
     if (P) { HIPCHK(hipMemcpy(dDoc, doc_ids, (size_t)P * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dW, tf, (size_t)P, hipMemcpyHostToDevice)); }
     ix->hPostOff.assign(offs, offs + T + 1); ix->hDf.assign(df, df + T);
-    // range skip tables for long lists: df >= 4 * nRanges (<= 1 B of table per posting)
+    // Range skip tables (nRanges+1 offsets per list): a workgroup finds a list's slice inside its doc range with one lookup
+    // instead of two ~log2(df)-step binary searches whose dependent L2 round trips every (query, range) workgroup would pay.
+    // HBM is plentiful, so every list of >= 64 postings gets one as long as the tables stay below 2^31 entries (8 GiB);
+    // otherwise the threshold doubles until they fit.
     int nR = ix->d.nRanges;
     std::vector<uint32_t> skipIdx(T, 0xFFFFFFFFu), skipTerms;
     uint64_t per = (uint64_t)nR + 1;
+    uint64_t thr = 64;
+    for (;; thr *= 2) {
+        uint64_t n = 0; for (uint32_t t = 0; t < T; t++) if (offs[t + 1] - offs[t] >= thr) n++;
+        if (n * per <= 0x7FFFFFFFull) break;
+    }
     for (uint32_t t = 0; t < T; t++) {
         uint64_t len = offs[t + 1] - offs[t];
-        if (len >= (uint64_t)4 * nR && len >= 256) { skipIdx[t] = (uint32_t)(skipTerms.size() * per); skipTerms.push_back(t); }
+        if (len >= thr) { skipIdx[t] = (uint32_t)(skipTerms.size() * per); skipTerms.push_back(t); }
     }
     uint32_t *dSkipIdx = nullptr, *dSkipTbl = nullptr, *dSkipTerms = nullptr;
     HIPCHK(dalloc(ix, &dSkipIdx, T)); HIPCHK(dalloc(ix, &dSkipTbl, skipTerms.size() * per));
@@ -338,6 +402,24 @@ int32_t infx_upload_prefix_docsets(infx_index* ix, uint32_t nsets, const uint64_
     if (nsets) { HIPCHK(hipMemcpy(dOff, offs, ((size_t)nsets + 1) * 8, hipMemcpyHostToDevice)); }
     else { uint64_t z = 0; HIPCHK(hipMemcpy(dOff, &z, 8, hipMemcpyHostToDevice)); }
     if (tot) HIPCHK(hipMemcpy(dDocs, docs, (size_t)tot * 4, hipMemcpyHostToDevice));
+    {   // range skip tables for the DocSets too (same layout as the posting lists')
+        if (!ix->haveDocs) return fail(INFX_EINVAL, "infx_upload_docs must precede infx_upload_prefix_docsets (range count)%s");
+        const int nR = ix->d.nRanges; const uint64_t per = (uint64_t)nR + 1;
+        std::vector<uint32_t> psSkip(std::max<uint32_t>(nsets, 1), 0xFFFFFFFFu), sets;
+        for (uint32_t k = 0; k < nsets; k++) if (offs[k + 1] - offs[k] >= 64 && (sets.size() + 1) * per <= 0x7FFFFFFFull) { psSkip[k] = (uint32_t)(sets.size() * per); sets.push_back(k); }
+        uint32_t *dPsSkip = nullptr, *dPsTbl = nullptr, *dSets = nullptr;
+        HIPCHK(dalloc(ix, &dPsSkip, psSkip.size())); HIPCHK(dalloc(ix, &dPsTbl, sets.size() * per));
+        HIPCHK(hipMemcpy(dPsSkip, psSkip.data(), psSkip.size() * 4, hipMemcpyHostToDevice));
+        if (!sets.empty()) {
+            HIPCHK(hipMalloc((void**)&dSets, sets.size() * 4));
+            HIPCHK(hipMemcpy(dSets, sets.data(), sets.size() * 4, hipMemcpyHostToDevice));
+            uint64_t n = sets.size() * per;
+            k_build_skip<<<(unsigned)((n + 255) / 256), 256>>>(dOff, dDocs, dSets, (uint32_t)sets.size(), dPsTbl, nR, ix->d.rshift);
+            HIPCHK(hipDeviceSynchronize());
+            hipFree(dSets);
+        }
+        ix->d.psSkip = dPsSkip; ix->d.psSkipTbl = dPsTbl;
+    }
     ix->d.psOff = dOff; ix->d.psDocs = dDocs; ix->d.nSets = nsets;
     if (nsets) ix->hPsOff.assign(offs, offs + nsets + 1); else ix->hPsOff.assign(1, 0);
     return INFX_OK;
@@ -354,7 +436,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     HIPCHK(hipSetDevice(ix->cfg.device));
     infx_stream* s = new infx_stream(); s->ix = ix;
     HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-    hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1};
+    hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1, &s->evP0, &s->evP1, &s->evF0, &s->evF1};
     for (auto e : ev) HIPCHK(hipEventCreate(e));
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
     *out = s; return INFX_OK;
@@ -363,24 +445,22 @@ void infx_stream_destroy(infx_stream* s) {
     if (!s) return;
     hipSetDevice(s->ix->cfg.device);
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
-                  s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow};
+                  s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
+                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr};
     for (void* p : ps) if (p) hipFree(p);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
-    hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1};
+    hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1, s->evP0, s->evP1, s->evF0, s->evF1};
     for (auto e : ev) hipEventDestroy(e);
     if (s->st) hipStreamDestroy(s->st);
     delete s;
 }
 
-int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
-                               uint32_t extra_n, const int32_t* extra_docs, infx_counts* counts_out) {
-    if (!s || !q || (nterms && !terms)) return fail(INFX_EINVAL, "null argument%s");
+// Everything of a Stage-1 accumulate launch up to (and including) the kernel: translation of the query terms into device
+// entries, arena bounds, uploads, launch.  No synchronisation.
+static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
+                           uint32_t extra_n, const int32_t* extra_docs) {
     infx_index* ix = s->ix;
-    if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
-    if (nq == 0) return INFX_OK;
-    HIPCHK(hipSetDevice(ix->cfg.device));
-    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     if ((uint64_t)nq * ix->d.nRanges > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nq * nRanges exceeds the grid limit; split the batch%s");
     // translate + capacity bound.  A virtual term given as a MEMBER LIST (infx_term.reserved == 1: extra_docs[extra_off..+len) are index
     // term ids) is expanded into one device entry per member, all sharing the term's idf / role / rank and a dedupe group.
@@ -408,7 +488,8 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
                 if (gen) qb += D.end - D.begin;
             } else if (tm.reserved == 2) {     // union built on the device by the last infx_union_build: extra_off = its index
                 if (tm.extra_off >= s->unionCount.size()) return fail(INFX_EINVAL, "virtual term refers to a union that was not built%s");
-                D.begin = s->unionBase[tm.extra_off]; D.end = s->unionBase[tm.extra_off + 1]; D.isVirtual = 4 | 2; D.skip = 0xFFFFFFFFu;
+                D.begin = s->unionBase[tm.extra_off]; D.end = s->unionBase[tm.extra_off + 1]; D.isVirtual = 4 | 2;
+                D.skip = (uint32_t)((uint64_t)tm.extra_off * (ix->d.nRanges + 1));     // k_union's per-range offsets are its skip table
                 dt.push_back(D); termOfEntry.push_back(-1);
                 if (gen) qb += D.end - D.begin;
             } else if (tm.reserved == 1) {
@@ -449,8 +530,8 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     }
     GROW(s->dQueries, s->capQueries, nq * sizeof(DevQuery));
     GROW(s->dTerms, s->capTerms, std::max<size_t>(1, dt.size()) * sizeof(DevTerm));
-    GROW(s->dExtra, s->capExtra, std::max<size_t>(1, extra_n) * 4);
-    GROW(s->dUDocs, s->capUDocs, 4);
+    GROW(s->dExtra, s->capExtra, ((size_t)extra_n + 4) * 4);
+    GROW(s->dUDocs, s->capUDocs, 16); GROW(s->dURange, s->capURange, 4);
     GROW(s->dBlockOut, s->capBlockOut, ((size_t)nq + 1) * 8);      // qBase
     GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * 4);        // qCursor
     GROW(s->dQBytes, s->capQBytes, (size_t)nq * 8);
@@ -491,6 +572,19 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evA1, s->st));
     s->timedAcc = true;
+    s->lastQ.assign(q, q + nq); s->lastNq = nq;
+    return INFX_OK;
+}
+
+int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
+                               uint32_t extra_n, const int32_t* extra_docs, infx_counts* counts_out) {
+    if (!s || !q || (nterms && !terms)) return fail(INFX_EINVAL, "null argument%s");
+    infx_index* ix = s->ix;
+    if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
+    if (nq == 0) return INFX_OK;
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    { int32_t rc_ = acc_enqueue(s, nq, q, nterms, terms, extra_n, extra_docs); if (rc_) return rc_; }
     uint32_t ovf = 0; std::vector<unsigned long long> qbytes(nq);
     if (counts_out) DOWN(counts_out, s->dCounts, (size_t)nq * INFX_NCLASS * 4);
     DOWN(&ovf, s->dOverflow, 4);
@@ -500,50 +594,6 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     s->lastAlgBytes = 0; for (auto b : qbytes) s->lastAlgBytes += b;
     s->lastQ.assign(q, q + nq); s->lastNq = nq;
     return INFX_OK;
-}
-
-// TieredCandidateSelector tier rules evaluated from class counts (see header of this file / DESIGN.md)
-static SelRule make_rule0(const infx_query& Q, const uint32_t* c) {
-    SelRule r{}; r.mode = Q.mode; r.depth = Q.depth; r.cutoffRank = 127; r.classMask = 0xFFFFFFFFu;
-    const long k = Q.depth;
-    if (Q.mode == INFX_MODE_AND) {
-        unsigned long long t0 = 0, t1 = 0;
-        for (int i = 0; i < 16; i++) { if (i & 1) t0 += c[i]; if (i & 2) t1 += c[i]; }
-        if ((long)t0 >= k * 2) { r.classMask = 1; return r; }                       // Tier 0 alone (:160-161)
-        unsigned long long g = t0; uint32_t gmask = 1;
-        if (Q.n_and >= 3 && (long)t0 < k * 3) { g = t1; gmask = 2 | 1; }            // Tier 1 (:165-171); T1 contains T0
-        if ((long)g < k * 5) {                                                      // Tier 2 (:174-234)
-            if (Q.df_s1 <= 0) { r.classMask = gmask; return r; }
-            if ((long)Q.df_s1 >= k * 10 || Q.df_s2 <= 0) { r.classMask = 4 | gmask; return r; }   // G u S1 == S1
-            r.classMask = 4 | 8 | gmask; return r;
-        }
-        r.classMask = gmask; return r;
-    }
-    if (Q.mode == INFX_MODE_DISJ) {
-        // SelectCandidatesDisjunctive (:260-319): ranks [0, n_and) are not low-quality, the rest are
-        int nElig = Q.n_and; bool hasSel = false; long local = 0; int cutoff = -1;
-        int nRanks = 0; for (int i = 127; i >= 0; i--) if (c[i]) { nRanks = i + 1; break; }
-        int totalRanks = std::max(nRanks, Q.df_s1);   // df_s1 carries the number of ranks in DISJ mode
-        for (int i = 0; i < totalRanks; i++) {
-            bool lowq = i >= nElig;
-            if (totalRanks > 1 && lowq && hasSel) continue;
-            cutoff = i; local += c[i];
-            if (!lowq && local > 0) hasSel = true;
-            if (local >= k * 100) break;
-        }
-        r.cutoffRank = cutoff; return r;
-    }
-    return r;
-}
-
-static SelRule make_rule(const infx_query& Q, const uint32_t* c) {
-    SelRule r = make_rule0(Q, c);
-    unsigned long long tot = 0;
-    if (Q.mode == INFX_MODE_AND) { for (int i = 0; i < 16; i++) if (i & r.classMask) tot += c[i]; }
-    else if (Q.mode == INFX_MODE_DISJ) { for (int i = 0; i <= r.cutoffRank && i < 128; i++) tot += c[i]; tot += 128; /* pre-seen docs (< 100) are not in the histogram */ }
-    else tot = c[1];
-    r.total = (uint32_t)std::min<unsigned long long>(tot, 0xFFFFFFFFull); r.pad = 0;
-    return r;
 }
 
 int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* counts, infx_hit* out, uint32_t* out_count) {
@@ -614,6 +664,180 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     return INFX_OK;
 }
 
+int32_t infx_upload_wordmatcher(infx_index* ix, uint64_t n_exact, const int32_t* exact_docs, uint64_t n_ld1, const int32_t* ld1_docs) {
+    if (!ix || (n_exact && !exact_docs) || (n_ld1 && !ld1_docs)) return fail(INFX_EINVAL, "null argument%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    int32_t *dE = nullptr, *dL = nullptr;
+    HIPCHK(dalloc(ix, &dE, (size_t)n_exact + 1)); HIPCHK(dalloc(ix, &dL, (size_t)n_ld1 + 1));
+    if (n_exact) HIPCHK(hipMemcpy(dE, exact_docs, (size_t)n_exact * 4, hipMemcpyHostToDevice));
+    if (n_ld1) HIPCHK(hipMemcpy(dL, ld1_docs, (size_t)n_ld1 * 4, hipMemcpyHostToDevice));
+    ix->d.wmExact = dE; ix->d.wmLd1 = dL; ix->nWmExact = n_exact; ix->nWmLd1 = n_ld1; ix->haveWm = true;
+    return INFX_OK;
+}
+
+static uint32_t pow2_at_least(uint32_t v, uint32_t lo) { uint32_t p = lo; while (p < v) p <<= 1; return p; }
+
+int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint32_t nterms, const infx_term* terms,
+                          uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq,
+                          uint32_t nlists, const infx_wm_list* lists, uint32_t owned_n, const int32_t* owned,
+                          int32_t depth, int32_t max_results, int32_t want_debug,
+                          int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags) {
+    if (!s || (nd && (!q || (nterms && !terms))) || (nq && (!fq || !cq || !out_keys || !out_scores || !out_counts)) || (nlists && !lists) || (owned_n && !owned))
+        return fail(INFX_EINVAL, "null argument%s");
+    infx_index* ix = s->ix;
+    if (!ix->havePostings || !ix->haveDocs || !ix->d.text) return fail(INFX_EINVAL, "index not uploaded%s");
+    if (ix->nranks > 1 || ix->d.docBase != 0) return fail(INFX_EINVAL, "infx_search_fused needs an unsharded index (sharded engines use the phase API)%s");
+    if (nq == 0) return INFX_OK;
+    if (nd > nq || max_results < 1 || depth < 1 || depth > ix->cfg.max_depth) return fail(INFX_EINVAL, "bad batch shape%s");
+    bool anyWm = false;
+    for (uint32_t i = 0; i < nq; i++) {
+        if (fq[i].dev >= (int32_t)nd) return fail(INFX_EINVAL, "fused query refers to a missing Stage-1 query%s");
+        if (fq[i].wm_count > INFX_MAX_WM_LISTS || (uint64_t)fq[i].wm_off + fq[i].wm_count > nlists) return fail(INFX_ECAPACITY, "too many WordMatcher lists for one query%s");
+        if (fq[i].wm_count) anyWm = true;
+        if ((fq[i].flags & INFX_FQ_COV) && !(fq[i].flags & INFX_FQ_SKIP) &&
+            (cq[i].num_tokens > INFX_MAX_QUERY_TOKENS || cq[i].text_len > INFX_MAX_QUERY_CHARS || cq[i].num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS))
+            return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope%s");
+    }
+    for (uint32_t l = 0; l < nlists; l++) {
+        const infx_wm_list& L = lists[l];
+        const uint64_t lim = L.src == 0 ? ix->nWmExact : (L.src == 1 ? ix->nWmLd1 : (L.src == 2 ? owned_n : 0));
+        if (L.off + L.len > lim) return fail(INFX_EINVAL, "WordMatcher list out of range%s");
+    }
+    if (anyWm && !ix->haveWm) return fail(INFX_EINVAL, "infx_upload_wordmatcher has not been called%s");
+    for (uint32_t i = 0; i < nd; i++) if (q[i].depth != depth) return fail(INFX_EINVAL, "all queries of a fused batch share one depth%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    if (nd) { int32_t rc_ = acc_enqueue(s, nd, q, nterms, terms, 0, nullptr); if (rc_) return rc_; }
+    else { HIPCHK(hipEventRecord(s->evA0, s->st)); HIPCHK(hipEventRecord(s->evA1, s->st)); }
+    const uint32_t stride = 2u * (uint32_t)depth, ncand = nq * stride;
+    const uint32_t Dp = pow2_at_least((uint32_t)depth, 2), Cp = pow2_at_least(stride, 2);
+    GROW(s->dRules, s->capRules, std::max<size_t>(1, nd) * sizeof(SelRule));
+    GROW(s->dHits, s->capHits, std::max<size_t>(1, (size_t)nd) * depth * sizeof(infx_hit));
+    GROW(s->dHitCount, s->capHitCount, std::max<size_t>(1, nd) * 4);
+    GROW(s->dFQueries, s->capFQueries, std::max<size_t>(1, nd) * sizeof(infx_query));
+    GROW(s->dFQ, s->capFQ, (size_t)nq * sizeof(infx_fused_query));
+    GROW(s->dFLists, s->capFLists, std::max<size_t>(1, nlists) * sizeof(infx_wm_list));
+    GROW(s->dFOwned, s->capFOwned, ((size_t)owned_n + 1) * 4);
+    GROW(s->dFS1, s->capFS1, (size_t)nq * depth * sizeof(infx_hit));
+    GROW(s->dFMeta, s->capFMeta, (size_t)nq * sizeof(FusedMeta));
+    GROW(s->dCovQ, s->capCovQ, (size_t)nq * sizeof(infx_cov_query));
+    GROW(s->dCovC, s->capCovC, (size_t)ncand * sizeof(infx_cov_cand));
+    GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
+    if (want_debug) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
+    GROW(s->dFKeys, s->capFKeys, (size_t)nq * max_results * 8);
+    GROW(s->dFScores, s->capFScores, (size_t)nq * max_results * 4);
+    GROW(s->dFTies, s->capFTies, (size_t)nq * max_results);
+    GROW(s->dFCounts, s->capFCounts, (size_t)nq * 4);
+    GROW(s->dFFlags, s->capFFlags, (size_t)nq * 4);
+    GROW(s->dFErr, s->capFErr, 4);
+    UP(s->dFQueries, q, (size_t)nd * sizeof(infx_query));
+    UP(s->dFQ, fq, (size_t)nq * sizeof(infx_fused_query));
+    UP(s->dFLists, lists, (size_t)nlists * sizeof(infx_wm_list));
+    UP(s->dFOwned, owned, (size_t)owned_n * 4);
+    UP(s->dCovQ, cq, (size_t)nq * sizeof(infx_cov_query));
+    HIPCHK(hipMemsetAsync(s->dFErr, 0, 4, s->st));
+    HIPCHK(hipMemsetAsync(s->dHitCount, 0, std::max<size_t>(1, nd) * 4, s->st));
+    Arena ar{s->arDoc, s->arScore, s->arCls, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
+             (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes};
+    HIPCHK(hipEventRecord(s->evS0, s->st));
+    if (nd) {
+        k_rules<<<(nd + 255) / 256, 256, 0, s->st>>>((const infx_query*)s->dFQueries, (const uint32_t*)s->dCounts, (SelRule*)s->dRules, nd);
+        k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->evS1, s->st));
+    HIPCHK(hipEventRecord(s->evP0, s->st));
+    {
+        const size_t Pp = std::max<size_t>(Dp, P2_CAP);
+        const size_t lds = (size_t)Dp * 4 * 4 + Pp * 4 + (size_t)P2_CAP * 4 + (size_t)Dp * 8 + (size_t)Dp * 2 + Pp + (size_t)P2_MAXLISTS * (8 + 4 + 4 + 4) + (P2_THREADS + 1) * 4 + 64;
+        k_prep2<<<nq, P2_THREADS, lds, s->st>>>(ix->d, (const infx_hit*)s->dHits, (const uint32_t*)s->dHitCount, depth, (const infx_fused_query*)s->dFQ,
+                                                 (const infx_wm_list*)s->dFLists, (const int32_t*)s->dFOwned, depth, (int)Dp,
+                                                 (infx_hit*)s->dFS1, (infx_cov_cand*)s->dCovC, (FusedMeta*)s->dFMeta);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->evP1, s->st));
+    HIPCHK(hipEventRecord(s->evC0, s->st));
+    k_stage2<<<(ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st>>>(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
+                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->evC1, s->st));
+    HIPCHK(hipEventRecord(s->evF0, s->st));
+    {
+        const size_t lds = (size_t)Cp * (8 + 4 + 4 + 2 + 1 + 1) + (P2_THREADS + 1) * 4 + 64;
+        k_finalize<<<nq, P2_THREADS, lds, s->st>>>(ix->d, (const infx_fused_query*)s->dFQ, (const FusedMeta*)s->dFMeta, (const infx_cov_cand*)s->dCovC,
+                                                    (const infx_cov_out*)s->dCovO, (const infx_hit*)s->dFS1, depth, (int)Cp, max_results,
+                                                    (long long*)s->dFKeys, (float*)s->dFScores, out_ties ? (uint8_t*)s->dFTies : nullptr,
+                                                    (uint32_t*)s->dFCounts, (uint32_t*)s->dFFlags, (uint32_t*)s->dFErr);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->evF1, s->st));
+    s->timedFused = true; s->timedSel = s->timedCov = true;
+    uint32_t ovf = 0, err = 0; std::vector<unsigned long long> qbytes(nd); std::vector<SelRule> rules(nd); std::vector<FusedMeta> metas(nq);
+    DOWN(metas.data(), s->dFMeta, (size_t)nq * sizeof(FusedMeta));
+    std::vector<int64_t> hKeys((size_t)nq * max_results); std::vector<float> hScores((size_t)nq * max_results); std::vector<uint8_t> hTies(out_ties ? (size_t)nq * max_results : 0);
+    DOWN(hKeys.data(), s->dFKeys, (size_t)nq * max_results * 8);
+    DOWN(hScores.data(), s->dFScores, (size_t)nq * max_results * 4);
+    if (out_ties) DOWN(hTies.data(), s->dFTies, (size_t)nq * max_results);
+    DOWN(out_counts, s->dFCounts, (size_t)nq * 4);
+    if (out_flags) DOWN(out_flags, s->dFFlags, (size_t)nq * 4);
+    DOWN(&err, s->dFErr, 4);
+    if (nd) { DOWN(&ovf, s->dOverflow, 4); DOWN(qbytes.data(), s->dQBytes, (size_t)nd * 8); DOWN(rules.data(), s->dRules, (size_t)nd * sizeof(SelRule)); }
+    SYNC();
+    if (ovf) return fail(INFX_ECAPACITY, "candidate arena overflow (bound violated)%s");
+    if (err) return fail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)%s");
+    for (uint32_t i = 0; i < nq; i++) {     // rows beyond a query's count stay untouched in the caller's buffers
+        const size_t o = (size_t)i * max_results, c = std::min<size_t>(out_counts[i], (size_t)max_results);
+        std::memcpy(out_keys + o, hKeys.data() + o, c * 8); std::memcpy(out_scores + o, hScores.data() + o, c * 4);
+        if (out_ties) std::memcpy(out_ties + o, hTies.data() + o, c);
+    }
+    s->lastAlgBytes = 0; for (auto b : qbytes) s->lastAlgBytes += b;
+    s->lastCandTotal = 0; for (auto& r : rules) s->lastCandTotal += r.total;
+    s->fusedNq = nq; s->fusedDepth = depth; s->fusedDebug = want_debug != 0;
+    s->fusedS1 = s->fusedCands = s->fusedTextBytes = 0;
+    for (auto& m : metas) { s->fusedS1 += m.s1Count; s->fusedCands += m.candCount; s->fusedTextBytes += (uint64_t)m.pad0 + ((uint64_t)m.pad1 << 32); }
+    return INFX_OK;
+}
+
+int32_t infx_fused_debug(infx_stream* s, infx_hit* s1, uint32_t* s1_counts, infx_cov_cand* cands, infx_cov_out* outs, int32_t* feat,
+                         uint32_t* cand_counts, uint32_t* run_cov, int32_t* idx01) {
+    if (!s || !s->fusedNq) return fail(INFX_EINVAL, "no fused batch to read back%s");
+    if (feat && !s->fusedDebug) return fail(INFX_EINVAL, "the last fused batch ran without want_debug%s");
+    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    const uint32_t nq = s->fusedNq; const size_t depth = (size_t)s->fusedDepth, ncand = (size_t)nq * 2 * depth;
+    std::vector<FusedMeta> metas(nq);
+    if (s1) DOWN(s1, s->dFS1, (size_t)nq * depth * sizeof(infx_hit));
+    if (cands) DOWN(cands, s->dCovC, ncand * sizeof(infx_cov_cand));
+    if (outs) DOWN(outs, s->dCovO, ncand * sizeof(infx_cov_out));
+    if (feat) DOWN(feat, s->dCovF, ncand * INFX_NFEAT * 4);
+    DOWN(metas.data(), s->dFMeta, (size_t)nq * sizeof(FusedMeta));
+    SYNC();
+    for (uint32_t i = 0; i < nq; i++) {
+        if (s1_counts) s1_counts[i] = metas[i].s1Count;
+        if (cand_counts) cand_counts[i] = metas[i].candCount;
+        if (run_cov) run_cov[i] = metas[i].runCov | (metas[i].wmAny << 1);
+        if (idx01) { idx01[2 * i] = metas[i].idx0; idx01[2 * i + 1] = metas[i].idx1; }
+    }
+    return INFX_OK;
+}
+
+int32_t infx_last_fused_stats(infx_stream* s, uint64_t* s1_rows, uint64_t* stage2_rows, uint64_t* stage2_text_bytes) {
+    if (!s) return fail(INFX_EINVAL, "null argument%s");
+    if (s1_rows) *s1_rows = s->fusedS1; if (stage2_rows) *stage2_rows = s->fusedCands; if (stage2_text_bytes) *stage2_text_bytes = s->fusedTextBytes;
+    return INFX_OK;
+}
+
+int32_t infx_last_fused_timings(infx_stream* s, float* ms5) {
+    if (!s || !ms5) return fail(INFX_EINVAL, "null argument%s");
+    if (s->timedFused) {
+        hipEventElapsedTime(&s->msFused[0], s->evA0, s->evA1); hipEventElapsedTime(&s->msFused[1], s->evS0, s->evS1);
+        hipEventElapsedTime(&s->msFused[2], s->evP0, s->evP1); hipEventElapsedTime(&s->msFused[3], s->evC0, s->evC1);
+        hipEventElapsedTime(&s->msFused[4], s->evF0, s->evF1);
+    }
+    for (int i = 0; i < 5; i++) ms5[i] = s->msFused[i];
+    return INFX_OK;
+}
+
 int32_t infx_last_timings(infx_stream* s, float* a, float* b, float* c) {
     if (!s) return fail(INFX_EINVAL, "null argument%s");
     if (s->timedAcc) hipEventElapsedTime(&s->msAcc, s->evA0, s->evA1);
@@ -649,7 +873,7 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     s->unionCount.assign(counts_out, counts_out + nv);
     s->unionBase.assign((size_t)nv + 1, 0);
     for (uint32_t v = 0; v < nv; v++) s->unionBase[v + 1] = s->unionBase[v] + counts_out[v];
-    GROW(s->dUDocs, s->capUDocs, std::max<size_t>(1, s->unionBase[nv]) * 4);
+    GROW(s->dUDocs, s->capUDocs, ((size_t)s->unionBase[nv] + 4) * 4);
     UP(s->dUBase, s->unionBase.data(), ((size_t)nv + 1) * 8);
     launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, (const unsigned long long*)s->dUBase, (int32_t*)s->dUDocs);
     HIPCHK(hipGetLastError());
