@@ -209,13 +209,16 @@ def main():
                    "parallelism": "single GPU" if world == 1 else (f"{world} document shards, count all-reduce + RCCL all-gather of per-shard top-500 + owner-scored Stage 2" if sharded
                                                                     else f"{world} independent replicas (one index per GPU, query stream split)")},
         "p50_batch_latency_ms": float(np.median(lat)),
+        # host phases of a batch (per session; sessions overlap): planning (text prep, term lookup, LD1 expansion, idf/roles),
+        # Stage-1 host part (phase API only), Stage-2 preparation (fused pipeline: WordMatcher descriptors + PrepareQuery),
+        # the wait for the device (fused: the whole device pipeline behind one synchronisation), host post-processing
         "stage_ms_per_step": {kk: float(np.mean([t[kk] for t in tim])) for kk in ("plan_ms", "stage1_ms", "prep2_ms", "stage2_ms", "post_ms",
-                                                                                  "k_accumulate_ms", "k_select_ms", "k_stage2_ms")},
+                                                                                  "k_accumulate_ms", "k_select_ms", "k_prep2_ms", "k_stage2_ms", "k_finalize_ms")},
         "roofline": {"kernel": "k_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": acc_ms,
                      "streamed_bytes_per_launch": streamed, "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
-                     "other_kernels_ms": {"k_select": float(np.mean([t["k_select_ms"] for t in roof])), "k_stage2": float(np.mean([t["k_stage2_ms"] for t in roof]))},
+                     "other_kernels_ms": {kk: float(np.mean([t[kk + "_ms"] for t in roof])) for kk in ("k_select", "k_prep2", "k_stage2", "k_finalize")},
                      "note": "achieved = SURVEY 8(d) algorithmic bytes / k_accumulate duration (HIP events, uncontended launch); ranges without "
                              "candidates are skipped, so fewer bytes are streamed than the algorithm nominally reads"},
         "setup_s": {"corpus_gen": t_gen, "index_build_and_upload": t_index, "host_threads": bthreads},

@@ -56,7 +56,7 @@ void    infx_engine_session_destroy(infx_session* s);
 int32_t infx_engine_session_search_batch(infx_session* s, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
                                          int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                          uint32_t* out_counts, uint32_t* out_flags);
-int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, float* kernel_ms3, uint64_t* alg3);
+int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, float* kernel_ms5, uint64_t* alg5);
 
 /* Document-sharded operation: every rank indexes the whole corpus on the host (global df / avgdl / N), uploads
  * its contiguous doc range, and a batch runs as four phases with the collectives in between:
@@ -80,11 +80,14 @@ int32_t infx_session_outs(infx_session* s, int32_t* outs3);
 int32_t infx_session_phase4(infx_session* s, const int32_t* merged_outs3, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                             uint32_t* out_counts, uint32_t* out_flags);
 
-/* host_ms5: plan, stage1 (incl. transfers), stage-2 prep, stage2 (incl. transfers), final ordering;
- * kernel_ms3: accumulate, select, stage2 kernel durations from HIP events on the launch stream;
+/* host_ms5: plan; Stage 1 incl. transfers (phase API only, 0 for the fused pipeline); Stage-2 preparation (fused pipeline:
+ * WordMatcher list descriptors + PrepareQuery); GPU stage (phase API: Stage 2 incl. transfers; fused: the whole device
+ * pipeline, one synchronisation); final ordering on the host (phase API only);
+ * kernel_ms5: accumulate, rules + select, stage2, and for the fused pipeline candidate assembly (k_prep2) and final ordering
+ * (k_finalize) — kernel durations from HIP events on the launch stream;
  * alg (5 entries): algorithmic bytes of the accumulate launch per SURVEY 8(d), Stage-2 candidate count, Stage-2 text bytes,
  * bytes the accumulate launch actually streamed, Stage-1 candidates. */
-int32_t infx_engine_last_timings(infx_engine* e, double* host_ms5, float* kernel_ms3, uint64_t* alg3);
+int32_t infx_engine_last_timings(infx_engine* e, double* host_ms5, float* kernel_ms5, uint64_t* alg5);
 
 /* ---- introspection used by the parity tests (host logic runs without a GPU) ---- */
 int32_t infx_engine_index_stats(infx_engine* e, int64_t* n_docs, int64_t* n_terms, int64_t* n_postings, float* avgdl);

@@ -267,7 +267,7 @@ static int32_t ph_plan_finish(infx_engine* e, infx_session* S, const uint32_t* g
 static int32_t ph_accumulate(infx_engine* e, infx_session* S) {
     Batch& B = *S->batch;
     B.counts.assign(B.nd, infx_counts{});
-    S->msAcc = S->msSel = S->msCov = 0; S->algBytes = 0;
+    S->msAcc = S->msSel = S->msCov = S->msPrep2 = S->msFin = 0; S->algBytes = 0;
     if (B.nd) {
         int32_t rc = infx_stage1_accumulate(S->stream, B.nd, B.dq.data(), (uint32_t)B.dterms.size(), B.dterms.data(), (uint32_t)B.extra.size(), B.extra.data(), B.counts.data());
         if (rc) { g_eerr = infx_last_error(); return rc; }
@@ -703,7 +703,7 @@ int32_t infx_engine_default_session(infx_engine* e, infx_session** out) { if (!e
 int32_t infx_engine_session_last_timings(infx_session* S, double* host_ms5, float* kernel_ms3, uint64_t* alg_bytes3) {
     if (!S) return efail(INFX_EINVAL, "null");
     if (host_ms5) { host_ms5[0] = S->tPrep1; host_ms5[1] = S->tStage1; host_ms5[2] = S->tPrep2; host_ms5[3] = S->tStage2; host_ms5[4] = S->tPost; }
-    if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; }
+    if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; kernel_ms3[3] = S->msPrep2; kernel_ms3[4] = S->msFin; }
     if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; }
     return INFX_OK;
 }
@@ -712,7 +712,7 @@ int32_t infx_engine_last_timings(infx_engine* e, double* host_ms5, float* kernel
     if (!e) return efail(INFX_EINVAL, "null");
     infx_session* S = e->def;
     if (host_ms5) { host_ms5[0] = S->tPrep1; host_ms5[1] = S->tStage1; host_ms5[2] = S->tPrep2; host_ms5[3] = S->tStage2; host_ms5[4] = S->tPost; }
-    if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; }
+    if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; kernel_ms3[3] = S->msPrep2; kernel_ms3[4] = S->msFin; }
     if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; }
     return INFX_OK;
 }

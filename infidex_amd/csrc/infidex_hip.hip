@@ -282,11 +282,13 @@ static void launch_union_any(infx_stream* s, uint32_t nv, const uint32_t* dOffs,
         default: launch_union<16384>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
     }
 }
-template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT) {
-    size_t lds = (size_t)(R / 32) * 8 + 8 + (size_t)ACC_CAP * 13 + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
+template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp) {
+    static const int cap = [] { const char* e = getenv("INFX_ACC_CAP"); int v = e ? atoi(e) : 0; return (v >= 64 && v <= 4096 && (v & 63) == 0) ? v : ACC_CAP_DEFAULT; }();
+    static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
+    size_t lds = (size_t)(R / 32) * 6 + 8 + (size_t)cap * (12 + (useGrp ? 1 : 0)) + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
     uint64_t blocks = (uint64_t)nq * s->ix->d.nRanges;
     k_accumulate<R><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT);
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, cap, useGrp, dbgSkip);
 }
 
 extern "C" {
@@ -467,7 +469,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     std::vector<DevQuery> dq(nq); std::vector<DevTerm> dt; dt.reserve(nterms + 64);
     std::vector<int32_t> termOfEntry; termOfEntry.reserve(nterms + 64);
     std::vector<unsigned long long> qbase((size_t)nq + 1);
-    unsigned long long bound = 0; int maxT = 1;
+    unsigned long long bound = 0; int maxT = 1, useGrp = 0;
     for (uint32_t i = 0; i < nq; i++) {
         const infx_query& Q = q[i];
         if (Q.num_terms > INFX_MAX_QUERY_TERMS || (uint64_t)Q.term_off + Q.num_terms > nterms) return fail(INFX_EINVAL, "bad term range%s");
@@ -495,6 +497,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
             } else if (tm.reserved == 1) {
                 if ((uint64_t)tm.extra_off + tm.extra_len > extra_n) return fail(INFX_EINVAL, "virtual term member list out of range%s");
                 if (++group > 255) return fail(INFX_ECAPACITY, "more than 255 fuzzy virtual terms in one query%s");
+                useGrp = 1;
                 for (uint32_t m = 0; m < tm.extra_len; m++) {
                     int32_t mt = extra_docs[tm.extra_off + m];
                     if (mt < 0 || mt >= ix->d.T) return fail(INFX_EINVAL, "member term id out of range%s");
@@ -562,12 +565,12 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
              (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes};
     HIPCHK(hipEventRecord(s->evA0, s->st));
     switch (ix->d.R) {
-        case 512: launch_acc<512>(s, nq, ar, maxT); break;
-        case 1024: launch_acc<1024>(s, nq, ar, maxT); break;
-        case 2048: launch_acc<2048>(s, nq, ar, maxT); break;
-        case 4096: launch_acc<4096>(s, nq, ar, maxT); break;
-        case 8192: launch_acc<8192>(s, nq, ar, maxT); break;
-        default: launch_acc<16384>(s, nq, ar, maxT); break;
+        case 512: launch_acc<512>(s, nq, ar, maxT, useGrp); break;
+        case 1024: launch_acc<1024>(s, nq, ar, maxT, useGrp); break;
+        case 2048: launch_acc<2048>(s, nq, ar, maxT, useGrp); break;
+        case 4096: launch_acc<4096>(s, nq, ar, maxT, useGrp); break;
+        case 8192: launch_acc<8192>(s, nq, ar, maxT, useGrp); break;
+        default: launch_acc<16384>(s, nq, ar, maxT, useGrp); break;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evA1, s->st));

@@ -195,10 +195,11 @@ class SearchEngine:
         return out
 
     def last_timings(self):
-        host = np.zeros(5, np.float64); kern = np.zeros(3, np.float32); alg = np.zeros(5, np.uint64)
+        host = np.zeros(5, np.float64); kern = np.zeros(5, np.float32); alg = np.zeros(5, np.uint64)
         self._check(self.L.infx_engine_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))
         return {"plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
                 "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
+                "k_prep2_ms": float(kern[3]), "k_finalize_ms": float(kern[4]),
                 "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2]),
                 "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4])}
 
@@ -292,10 +293,11 @@ class Session:
         return keys, scores, ties, counts, flags
 
     def last_timings(self):
-        host = np.zeros(5, np.float64); kern = np.zeros(3, np.float32); alg = np.zeros(5, np.uint64)
+        host = np.zeros(5, np.float64); kern = np.zeros(5, np.float32); alg = np.zeros(5, np.uint64)
         self.engine._check(self.L.infx_engine_session_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))
         return {"plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
                 "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
+                "k_prep2_ms": float(kern[3]), "k_finalize_ms": float(kern[4]),
                 "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2]),
                 "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4])}
 
