@@ -214,6 +214,21 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
                           uint32_t nlists, const infx_wm_list* lists, uint32_t owned_n, const int32_t* owned,
                           int32_t depth, int32_t max_results, int32_t want_debug,
                           int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags);
+/* Document-sharded operation: the same device stages, cut where the collectives go. Rows carry GLOBAL internal ids.
+ *   infx_stage1_accumulate (local) -> all-reduce(sum) of the class histograms
+ *   infx_shard_select   : tier rules from the GLOBAL counts + local top-`depth`      -> all-gather of hits / hit counts (RCCL)
+ *   infx_shard_stage2   : merge of the nshards lists, candidate assembly, Stage 2 on the rows whose document this shard holds
+ *                         (all other rows are zero)                                  -> all-reduce(sum) of outs (nq x 2*depth x 12 B)
+ *   infx_shard_finalize : final ordering / truncation from the merged rows (identical on every rank).
+ * Every shard needs the GLOBAL DocumentKey table (infx_upload_doc_keys_all) and the WordMatcher lists (global ids). */
+int32_t infx_upload_doc_keys_all(infx_index* idx, uint32_t total_docs, const int64_t* keys);
+int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global_counts, int32_t depth, infx_hit* hits_out, uint32_t* hitcount_out);
+int32_t infx_shard_stage2(infx_stream* s, int32_t nshards, uint32_t nd, const infx_hit* all_hits /* nshards x nd x depth */, const uint32_t* all_hitcounts,
+                          uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq, uint32_t nlists, const infx_wm_list* lists,
+                          uint32_t owned_n, const int32_t* owned, int32_t depth, int32_t max_results, int32_t want_debug, infx_cov_out* outs_out);
+int32_t infx_shard_finalize(infx_stream* s, uint32_t nq, const infx_cov_out* merged_outs, int32_t depth, int32_t max_results,
+                            int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags);
+
 /* After an infx_search_fused call with want_debug != 0: the intermediate device results (parity tests / introspection).
  * s1: nq x depth (ConsolidateSegments order) + counts; cands/outs/feat: nq x 2*depth rows, cand_counts[i] of them valid;
  * idx01: nq x 2 (documents with docIndex 0 / 1, -1 if absent).  Any pointer may be NULL. */

@@ -161,6 +161,8 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
             }
             if (!rc) rc = infx_upload_prefix_docsets(e->dev, (uint32_t)ns, po.data(), pd.data());
             if (!rc) rc = infx_set_shard(e->dev, e->rank, e->nranks, sb, ix.N);
+            if (!rc && ix.cfg.wordMatcher) rc = infx_upload_wordmatcher(e->dev, ix.wmExact.doc.size(), ix.wmExact.doc.data(), ix.wmLd1.doc.size(), ix.wmLd1.doc.data());
+            if (!rc) rc = infx_upload_doc_keys_all(e->dev, (uint32_t)ix.N, ix.docKey.data());
         }
         if (!rc) rc = infx_stream_create(e->dev, &e->def->stream);
         if (rc) { g_eerr = infx_last_error(); return rc; }
@@ -514,18 +516,15 @@ static int32_t ph_finalize(infx_engine* e, infx_session* S, const infx_cov_out* 
     return INFX_OK;
 }
 
-// Unsharded engines: the whole batch on the device with one synchronisation (infx_search_fused).  The host keeps what needs
-// its dictionaries: text preparation, term lookup, LD1 expansion, idf / roles (ph_plan*), and per query the WordMatcher list
-// descriptors (WordMatcher.Lookup, WordMatcher.cs:95-186) + CoverageEngine.PrepareQuery.
-static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
-                                  int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
-                                  uint32_t* out_counts, uint32_t* out_flags) {
-    int32_t rc = ph_plan(e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
-    rc = ph_plan_finish(e, S, S->batch->pendingCounts.data()); if (rc) return rc;
-    Batch& B = *S->batch; const HostIndex& ix = e->ix; const int threads = e->threads;
+// Per-query inputs of the device pipeline that need the host dictionaries: flags, WordMatcher list descriptors (WordMatcher.Lookup,
+// WordMatcher.cs:95-186; affix hits are copied into `owned`), CoverageEngine.PrepareQuery.
+struct FusedIn { std::vector<infx_fused_query> fq; std::vector<infx_cov_query> cq; std::vector<infx_wm_list> lists; std::vector<int32_t> owned; };
+static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_results, int32_t enable_coverage, FusedIn& F) {
+    Batch& B = *S->batch; const HostIndex& ix = e->ix; const int threads = e->threads; const uint32_t nq = B.nq;
     std::vector<QueryPlan>& plans = S->lastPlans;
+    auto& fq = F.fq; auto& cq = F.cq; auto& lists = F.lists; auto& owned = F.owned;
     const bool covEnabled = ix.cfg.enableCoverage && enable_coverage;
-    std::vector<infx_fused_query> fq(nq); std::vector<infx_cov_query> cq(nq);
+    fq.assign(nq, infx_fused_query{}); cq.assign(nq, infx_cov_query{});
     std::vector<std::vector<infx_wm_list>> qLists(nq); std::vector<std::vector<int32_t>> qOwned(nq);
     std::vector<int32_t> covErr(nq, 0);
     const int32_t* exB = ix.wmExact.doc.data(); const int32_t* exE = exB + ix.wmExact.doc.size();
@@ -556,7 +555,7 @@ static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, 
         }
     });
     for (uint32_t i = 0; i < nq; i++) if (covErr[i]) return efail(covErr[i], "query exceeds the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length)");
-    std::vector<infx_wm_list> lists; std::vector<int32_t> owned;
+    lists.clear(); owned.clear();
     for (uint32_t i = 0; i < nq; i++) {
         fq[i].wm_off = (uint32_t)lists.size(); fq[i].wm_count = (uint32_t)qLists[i].size();
         if (qLists[i].size() > INFX_MAX_WM_LISTS) return efail(INFX_ECAPACITY, "a query needs more than INFX_MAX_WM_LISTS WordMatcher lists");
@@ -564,6 +563,20 @@ static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, 
         owned.insert(owned.end(), qOwned[i].begin(), qOwned[i].end());
     }
     if (owned.size() > 0xFFFFFFF0ull) return efail(INFX_ECAPACITY, "affix matches of this batch exceed 2^32 ids; split the batch");
+    return INFX_OK;
+}
+
+// Unsharded engines: the whole batch on the device with one synchronisation (infx_search_fused).  The host keeps what needs
+// its dictionaries: text preparation, term lookup, LD1 expansion, idf / roles (ph_plan*), and per query the WordMatcher list
+// descriptors (WordMatcher.Lookup, WordMatcher.cs:95-186) + CoverageEngine.PrepareQuery.
+static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
+                                  int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
+                                  uint32_t* out_counts, uint32_t* out_flags) {
+    int32_t rc = ph_plan(e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
+    rc = ph_plan_finish(e, S, S->batch->pendingCounts.data()); if (rc) return rc;
+    Batch& B = *S->batch; const HostIndex& ix = e->ix;
+    FusedIn FI; rc = build_fused_inputs(e, S, max_results, enable_coverage, FI); if (rc) return rc;
+    auto& fq = FI.fq; auto& cq = FI.cq; auto& lists = FI.lists; auto& owned = FI.owned;
     B.t2 = now_ms();
     const bool dbg = e->cfg.want_features != 0;
     rc = infx_search_fused(S->stream, B.nd, B.dq.data(), (uint32_t)B.dterms.size(), B.dterms.data(), nq, fq.data(), cq.data(),
@@ -678,15 +691,52 @@ int32_t infx_session_counts(infx_session* S, uint32_t* counts) {   // nd x INFX_
 }
 int32_t infx_session_phase2(infx_session* S, const uint32_t* global_counts, infx_hit* hits, uint32_t* hitcounts) {
     if (!S || !global_counts) return efail(INFX_EINVAL, "null");
-    int32_t rc = ph_select(S->e, S, (const infx_counts*)global_counts); if (rc) return rc;
+    static const bool hostPhases = getenv("INFX_PHASED") != nullptr;      // the original host-side candidate assembly / final ordering
+    if (hostPhases) {
+        int32_t rc = ph_select(S->e, S, (const infx_counts*)global_counts); if (rc) return rc;
+        if (hits) std::memcpy(hits, S->lastHits.data(), S->lastHits.size() * sizeof(infx_hit));
+        if (hitcounts) std::memcpy(hitcounts, S->lastHitCount.data(), S->lastHitCount.size() * 4);
+        return INFX_OK;
+    }
+    Batch& B = *S->batch;
+    S->lastHits.assign((size_t)B.nd * B.depth, infx_hit{0, 0.f}); S->lastHitCount.assign(B.nd, 0); S->lastStride = B.depth;
+    if (B.nd) {
+        int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, S->lastHits.data(), S->lastHitCount.data());
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+        infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
+        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates);
+        uint64_t ab = 0, nh = 0;
+        for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)S->e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
+        for (uint32_t c : S->lastHitCount) nh += c;
+        S->algBytes = ab + S->s1Candidates * 4ull + nh * 12ull;
+    }
     if (hits) std::memcpy(hits, S->lastHits.data(), S->lastHits.size() * sizeof(infx_hit));
     if (hitcounts) std::memcpy(hitcounts, S->lastHitCount.data(), S->lastHitCount.size() * 4);
+    B.t2 = now_ms();
     return INFX_OK;
 }
 int32_t infx_session_phase3(infx_session* S, int32_t W, const infx_hit* all_hits, const uint32_t* all_counts, int32_t max_results, int32_t enable_coverage, uint64_t* ncand) {
     if (!S || W < 1 || max_results < 1) return efail(INFX_EINVAL, "bad arguments");
-    int32_t rc = ph_stage2(S->e, S, W, all_hits, all_counts, max_results, enable_coverage); if (rc) return rc;
-    if (ncand) *ncand = S->lastCands.size();
+    static const bool hostPhases = getenv("INFX_PHASED") != nullptr;
+    if (hostPhases) {
+        int32_t rc = ph_stage2(S->e, S, W, all_hits, all_counts, max_results, enable_coverage); if (rc) return rc;
+        if (ncand) *ncand = S->lastCands.size();
+        return INFX_OK;
+    }
+    infx_engine* e = S->e; Batch& B = *S->batch;
+    B.maxResults = max_results;
+    FusedIn FI; int32_t rc = build_fused_inputs(e, S, max_results, enable_coverage, FI); if (rc) return rc;
+    B.t3 = now_ms();
+    S->lastOuts.assign((size_t)B.nq * 2 * B.depth, infx_cov_out{});
+    if (B.nq) {
+        rc = infx_shard_stage2(S->stream, W, B.nd, all_hits, all_counts, B.nq, FI.fq.data(), FI.cq.data(), (uint32_t)FI.lists.size(), FI.lists.data(),
+                               (uint32_t)FI.owned.size(), FI.owned.data(), B.depth, max_results, 0, S->lastOuts.data());
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+        float ms5[5] = {0, 0, 0, 0, 0}; infx_last_fused_timings(S->stream, ms5); S->msPrep2 = ms5[2]; S->msCov = ms5[3];
+        infx_last_fused_stats(S->stream, nullptr, &S->s2Candidates, &S->s2TextBytes);
+    }
+    if (ncand) *ncand = S->lastOuts.size();
+    B.t4 = now_ms();
     return INFX_OK;
 }
 int32_t infx_session_outs(infx_session* S, int32_t* outs3) {   // ncand x 3 int32 words; zeros for candidates another shard owns
@@ -696,7 +746,17 @@ int32_t infx_session_outs(infx_session* S, int32_t* outs3) {   // ncand x 3 int3
 }
 int32_t infx_session_phase4(infx_session* S, const int32_t* merged_outs3, int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags) {
     if (!S || !merged_outs3 || !out_keys || !out_scores || !out_counts) return efail(INFX_EINVAL, "null");
-    return ph_finalize(S->e, S, (const infx_cov_out*)merged_outs3, out_keys, out_scores, out_ties, out_counts, out_flags);
+    static const bool hostPhases = getenv("INFX_PHASED") != nullptr;
+    if (hostPhases) return ph_finalize(S->e, S, (const infx_cov_out*)merged_outs3, out_keys, out_scores, out_ties, out_counts, out_flags);
+    Batch& B = *S->batch;
+    if (B.nq) {
+        int32_t rc = infx_shard_finalize(S->stream, B.nq, (const infx_cov_out*)merged_outs3, B.depth, B.maxResults, out_keys, out_scores, out_ties, out_counts, out_flags);
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+        float ms5[5] = {0, 0, 0, 0, 0}; infx_last_fused_timings(S->stream, ms5); S->msFin = ms5[4];
+    }
+    double t5 = now_ms();
+    S->tPrep1 = B.t1 - B.t0; S->tStage1 = B.t2 - B.t1; S->tPrep2 = B.t3 - B.t2; S->tStage2 = B.t4 - B.t3; S->tPost = t5 - B.t4;
+    return INFX_OK;
 }
 int32_t infx_engine_default_session(infx_engine* e, infx_session** out) { if (!e || !out) return INFX_EINVAL; *out = e->def; return INFX_OK; }
 

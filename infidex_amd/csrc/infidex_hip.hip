@@ -46,6 +46,7 @@ struct DevIndex {
     const uint32_t* psSkipTbl; // nRanges+1 offsets (relative to psOff[k]) per skipped set
     const int32_t* wmExact;    // WordMatcher exact-word doc lists (infx_upload_wordmatcher), global ids
     const int32_t* wmLd1;      // WordMatcher symmetric-delete doc lists
+    const int64_t* docKeyAll;  // DocumentKey by GLOBAL internal id (== docKey when unsharded)
     const uint64_t* psOff; const int32_t* psDocs; uint32_t nSets;
 };
 
@@ -180,8 +181,8 @@ struct infx_stream {
     hipStream_t st = nullptr;
     hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1;
     // fused pipeline workspaces
-    void *dFQ = nullptr, *dFLists = nullptr, *dFOwned = nullptr, *dFS1 = nullptr, *dFMeta = nullptr, *dFQueries = nullptr, *dFKeys = nullptr, *dFScores = nullptr, *dFTies = nullptr, *dFCounts = nullptr, *dFFlags = nullptr, *dFErr = nullptr;
-    size_t capFQ = 0, capFLists = 0, capFOwned = 0, capFS1 = 0, capFMeta = 0, capFQueries = 0, capFKeys = 0, capFScores = 0, capFTies = 0, capFCounts = 0, capFFlags = 0, capFErr = 0;
+    void *dFQ = nullptr, *dFLists = nullptr, *dFOwned = nullptr, *dFS1 = nullptr, *dFMeta = nullptr, *dFQueries = nullptr, *dFKeys = nullptr, *dFScores = nullptr, *dFTies = nullptr, *dFCounts = nullptr, *dFFlags = nullptr, *dFErr = nullptr, *dFHitsAll = nullptr, *dFHcAll = nullptr;
+    size_t capFQ = 0, capFLists = 0, capFOwned = 0, capFS1 = 0, capFMeta = 0, capFQueries = 0, capFKeys = 0, capFScores = 0, capFTies = 0, capFCounts = 0, capFFlags = 0, capFErr = 0, capFHitsAll = 0, capFHcAll = 0;
     uint64_t fusedS1 = 0, fusedCands = 0, fusedTextBytes = 0;
     uint32_t fusedNq = 0; int fusedDepth = 0; bool fusedDebug = false, timedFused = false; float msFused[5] = {0, 0, 0, 0, 0};
     // device workspaces (grown on demand)
@@ -344,7 +345,7 @@ int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float
         int R = N >= (4u << 20) ? 8192 : N >= (1u << 20) ? 4096 : N >= (1u << 18) ? 2048 : 1024;
         ix->d.R = R; ix->d.rshift = __builtin_ctz(R);
     }
-    ix->d.N = (int32_t)N; ix->d.docNorm = dNorm; ix->d.docKey = dKey; ix->d.textOff = dTO; ix->d.text = dTx;
+    ix->d.N = (int32_t)N; ix->d.docNorm = dNorm; ix->d.docKey = dKey; if (!ix->d.docKeyAll) ix->d.docKeyAll = dKey; ix->d.textOff = dTO; ix->d.text = dTx;
     ix->d.nRanges = (int32_t)(((uint64_t)N + ix->d.R - 1) >> ix->d.rshift);
     if (ix->d.nRanges == 0) ix->d.nRanges = 1;
     if (ix->d.totalDocs == 0) ix->d.totalDocs = (int32_t)N;
@@ -448,7 +449,7 @@ void infx_stream_destroy(infx_stream* s) {
     hipSetDevice(s->ix->cfg.device);
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
-                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr};
+                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll};
     for (void* p : ps) if (p) hipFree(p);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
@@ -657,7 +658,7 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     UP(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand));
     HIPCHK(hipEventRecord(s->evC0, s->st));
     k_stage2<<<(ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st>>>(ix->d, (const infx_cov_query*)s->dCovQ, nq,
-                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr);
+                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
     s->timedCov = true;
@@ -678,19 +679,12 @@ int32_t infx_upload_wordmatcher(infx_index* ix, uint64_t n_exact, const int32_t*
     return INFX_OK;
 }
 
+
 static uint32_t pow2_at_least(uint32_t v, uint32_t lo) { uint32_t p = lo; while (p < v) p <<= 1; return p; }
 
-int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint32_t nterms, const infx_term* terms,
-                          uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq,
-                          uint32_t nlists, const infx_wm_list* lists, uint32_t owned_n, const int32_t* owned,
-                          int32_t depth, int32_t max_results, int32_t want_debug,
-                          int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags) {
-    if (!s || (nd && (!q || (nterms && !terms))) || (nq && (!fq || !cq || !out_keys || !out_scores || !out_counts)) || (nlists && !lists) || (owned_n && !owned))
-        return fail(INFX_EINVAL, "null argument%s");
-    infx_index* ix = s->ix;
-    if (!ix->havePostings || !ix->haveDocs || !ix->d.text) return fail(INFX_EINVAL, "index not uploaded%s");
-    if (ix->nranks > 1 || ix->d.docBase != 0) return fail(INFX_EINVAL, "infx_search_fused needs an unsharded index (sharded engines use the phase API)%s");
-    if (nq == 0) return INFX_OK;
+// ---- fused pipeline pieces (shared by infx_search_fused and the sharded stage API) ------------------------------------------
+static int32_t fused_check_queries(infx_index* ix, uint32_t nd, uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq,
+                                   uint32_t nlists, const infx_wm_list* lists, uint32_t owned_n, int32_t depth, int32_t max_results) {
     if (nd > nq || max_results < 1 || depth < 1 || depth > ix->cfg.max_depth) return fail(INFX_EINVAL, "bad batch shape%s");
     bool anyWm = false;
     for (uint32_t i = 0; i < nq; i++) {
@@ -707,38 +701,17 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
         if (L.off + L.len > lim) return fail(INFX_EINVAL, "WordMatcher list out of range%s");
     }
     if (anyWm && !ix->haveWm) return fail(INFX_EINVAL, "infx_upload_wordmatcher has not been called%s");
-    for (uint32_t i = 0; i < nd; i++) if (q[i].depth != depth) return fail(INFX_EINVAL, "all queries of a fused batch share one depth%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
-    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
-    if (nd) { int32_t rc_ = acc_enqueue(s, nd, q, nterms, terms, 0, nullptr); if (rc_) return rc_; }
-    else { HIPCHK(hipEventRecord(s->evA0, s->st)); HIPCHK(hipEventRecord(s->evA1, s->st)); }
-    const uint32_t stride = 2u * (uint32_t)depth, ncand = nq * stride;
-    const uint32_t Dp = pow2_at_least((uint32_t)depth, 2), Cp = pow2_at_least(stride, 2);
+    return INFX_OK;
+}
+
+// k_rules (from the class histogram in s->dCounts) + k_select -> s->dHits / s->dHitCount (stride = depth)
+static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth) {
+    infx_index* ix = s->ix;
     GROW(s->dRules, s->capRules, std::max<size_t>(1, nd) * sizeof(SelRule));
     GROW(s->dHits, s->capHits, std::max<size_t>(1, (size_t)nd) * depth * sizeof(infx_hit));
     GROW(s->dHitCount, s->capHitCount, std::max<size_t>(1, nd) * 4);
     GROW(s->dFQueries, s->capFQueries, std::max<size_t>(1, nd) * sizeof(infx_query));
-    GROW(s->dFQ, s->capFQ, (size_t)nq * sizeof(infx_fused_query));
-    GROW(s->dFLists, s->capFLists, std::max<size_t>(1, nlists) * sizeof(infx_wm_list));
-    GROW(s->dFOwned, s->capFOwned, ((size_t)owned_n + 1) * 4);
-    GROW(s->dFS1, s->capFS1, (size_t)nq * depth * sizeof(infx_hit));
-    GROW(s->dFMeta, s->capFMeta, (size_t)nq * sizeof(FusedMeta));
-    GROW(s->dCovQ, s->capCovQ, (size_t)nq * sizeof(infx_cov_query));
-    GROW(s->dCovC, s->capCovC, (size_t)ncand * sizeof(infx_cov_cand));
-    GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
-    if (want_debug) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
-    GROW(s->dFKeys, s->capFKeys, (size_t)nq * max_results * 8);
-    GROW(s->dFScores, s->capFScores, (size_t)nq * max_results * 4);
-    GROW(s->dFTies, s->capFTies, (size_t)nq * max_results);
-    GROW(s->dFCounts, s->capFCounts, (size_t)nq * 4);
-    GROW(s->dFFlags, s->capFFlags, (size_t)nq * 4);
-    GROW(s->dFErr, s->capFErr, 4);
-    UP(s->dFQueries, q, (size_t)nd * sizeof(infx_query));
-    UP(s->dFQ, fq, (size_t)nq * sizeof(infx_fused_query));
-    UP(s->dFLists, lists, (size_t)nlists * sizeof(infx_wm_list));
-    UP(s->dFOwned, owned, (size_t)owned_n * 4);
-    UP(s->dCovQ, cq, (size_t)nq * sizeof(infx_cov_query));
-    HIPCHK(hipMemsetAsync(s->dFErr, 0, 4, s->st));
+    UP(s->dFQueries, s->lastQ.data(), (size_t)nd * sizeof(infx_query));
     HIPCHK(hipMemsetAsync(s->dHitCount, 0, std::max<size_t>(1, nd) * 4, s->st));
     Arena ar{s->arDoc, s->arScore, s->arCls, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
              (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes};
@@ -749,11 +722,39 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evS1, s->st));
+    s->timedSel = true;
+    return INFX_OK;
+}
+
+// uploads the per-query tables, then k_prep2 (merging W per-shard hit lists) + k_stage2 -> s->dCovC / s->dCovO / s->dFMeta / s->dFS1
+static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, const infx_hit* dHitsAll, const uint32_t* dHcAll,
+                                         uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq, uint32_t nlists, const infx_wm_list* lists,
+                                         uint32_t owned_n, const int32_t* owned, int32_t depth, int32_t want_debug) {
+    infx_index* ix = s->ix;
+    const uint32_t stride = 2u * (uint32_t)depth, ncand = nq * stride;
+    const uint32_t Dp = pow2_at_least((uint32_t)depth, 8);
+    const uint32_t Dall = W > 1 ? pow2_at_least((uint32_t)W * (uint32_t)depth, 8) : 0;
+    if (Dall > 8192) return fail(INFX_ECAPACITY, "shards x depth exceeds the in-LDS merge (8192 rows); merge hierarchically%s");
+    GROW(s->dFQ, s->capFQ, (size_t)nq * sizeof(infx_fused_query));
+    GROW(s->dFLists, s->capFLists, std::max<size_t>(1, nlists) * sizeof(infx_wm_list));
+    GROW(s->dFOwned, s->capFOwned, ((size_t)owned_n + 1) * 4);
+    GROW(s->dFS1, s->capFS1, (size_t)nq * depth * sizeof(infx_hit));
+    GROW(s->dFMeta, s->capFMeta, (size_t)nq * sizeof(FusedMeta));
+    GROW(s->dCovQ, s->capCovQ, (size_t)nq * sizeof(infx_cov_query));
+    GROW(s->dCovC, s->capCovC, (size_t)ncand * sizeof(infx_cov_cand));
+    GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
+    if (want_debug) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
+    UP(s->dFQ, fq, (size_t)nq * sizeof(infx_fused_query));
+    UP(s->dFLists, lists, (size_t)nlists * sizeof(infx_wm_list));
+    UP(s->dFOwned, owned, (size_t)owned_n * 4);
+    UP(s->dCovQ, cq, (size_t)nq * sizeof(infx_cov_query));
+    HIPCHK(hipMemsetAsync(s->dCovO, 0, (size_t)ncand * sizeof(infx_cov_out), s->st));
     HIPCHK(hipEventRecord(s->evP0, s->st));
     {
         const size_t Pp = std::max<size_t>(Dp, P2_CAP);
-        const size_t lds = (size_t)Dp * 4 * 4 + Pp * 4 + (size_t)P2_CAP * 4 + (size_t)Dp * 8 + (size_t)Dp * 2 + Pp + (size_t)P2_MAXLISTS * (8 + 4 + 4 + 4) + (P2_THREADS + 1) * 4 + 64;
-        k_prep2<<<nq, P2_THREADS, lds, s->st>>>(ix->d, (const infx_hit*)s->dHits, (const uint32_t*)s->dHitCount, depth, (const infx_fused_query*)s->dFQ,
+        const size_t lds = (size_t)Dp * 4 * 4 + Pp * 4 + (size_t)P2_CAP * 4 + (size_t)Dp * 8 + (size_t)Dp * 2 + Pp + (size_t)P2_MAXLISTS * (8 + 4 + 4 + 4) + (P2_THREADS + 2) * 4 + (size_t)Dall * 8 + 64;
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_prep2<<<nq, P2_THREADS, lds, s->st>>>(ix->d, dHitsAll, dHcAll, depth, W, (int)nd, (int)Dall, (const infx_fused_query*)s->dFQ,
                                                  (const infx_wm_list*)s->dFLists, (const int32_t*)s->dFOwned, depth, (int)Dp,
                                                  (infx_hit*)s->dFS1, (infx_cov_cand*)s->dCovC, (FusedMeta*)s->dFMeta);
     }
@@ -761,43 +762,164 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
     HIPCHK(hipEventRecord(s->evP1, s->st));
     HIPCHK(hipEventRecord(s->evC0, s->st));
     k_stage2<<<(ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st>>>(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
-                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr);
+                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
+    s->timedCov = true;
+    s->fusedNq = nq; s->fusedDepth = depth; s->fusedDebug = want_debug != 0;
+    return INFX_OK;
+}
+
+// k_finalize over s->dCovC / s->dCovO / s->dFMeta / s->dFS1 -> result rows in s->dFKeys ...
+static int32_t fused_enqueue_finalize(infx_stream* s, uint32_t nq, int32_t depth, int32_t max_results, bool ties) {
+    infx_index* ix = s->ix;
+    const uint32_t Cp = pow2_at_least(2u * (uint32_t)depth, 8);
+    GROW(s->dFKeys, s->capFKeys, (size_t)nq * max_results * 8);
+    GROW(s->dFScores, s->capFScores, (size_t)nq * max_results * 4);
+    GROW(s->dFTies, s->capFTies, (size_t)nq * max_results);
+    GROW(s->dFCounts, s->capFCounts, (size_t)nq * 4);
+    GROW(s->dFFlags, s->capFFlags, (size_t)nq * 4);
+    GROW(s->dFErr, s->capFErr, 4);
+    HIPCHK(hipMemsetAsync(s->dFErr, 0, 4, s->st));
     HIPCHK(hipEventRecord(s->evF0, s->st));
-    {
-        const size_t lds = (size_t)Cp * (8 + 4 + 4 + 2 + 1 + 1) + (P2_THREADS + 1) * 4 + 64;
-        k_finalize<<<nq, P2_THREADS, lds, s->st>>>(ix->d, (const infx_fused_query*)s->dFQ, (const FusedMeta*)s->dFMeta, (const infx_cov_cand*)s->dCovC,
-                                                    (const infx_cov_out*)s->dCovO, (const infx_hit*)s->dFS1, depth, (int)Cp, max_results,
-                                                    (long long*)s->dFKeys, (float*)s->dFScores, out_ties ? (uint8_t*)s->dFTies : nullptr,
-                                                    (uint32_t*)s->dFCounts, (uint32_t*)s->dFFlags, (uint32_t*)s->dFErr);
-    }
+    const size_t lds = (size_t)Cp * (8 + 4 + 4 + 2 + 1 + 1) + (P2_THREADS + 1) * 4 + 64;
+    k_finalize<<<nq, P2_THREADS, lds, s->st>>>(ix->d, (const infx_fused_query*)s->dFQ, (const FusedMeta*)s->dFMeta, (const infx_cov_cand*)s->dCovC,
+                                                (const infx_cov_out*)s->dCovO, (const infx_hit*)s->dFS1, depth, (int)Cp, max_results,
+                                                (long long*)s->dFKeys, (float*)s->dFScores, ties ? (uint8_t*)s->dFTies : nullptr,
+                                                (uint32_t*)s->dFCounts, (uint32_t*)s->dFFlags, (uint32_t*)s->dFErr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evF1, s->st));
-    s->timedFused = true; s->timedSel = s->timedCov = true;
-    uint32_t ovf = 0, err = 0; std::vector<unsigned long long> qbytes(nd); std::vector<SelRule> rules(nd); std::vector<FusedMeta> metas(nq);
-    DOWN(metas.data(), s->dFMeta, (size_t)nq * sizeof(FusedMeta));
-    std::vector<int64_t> hKeys((size_t)nq * max_results); std::vector<float> hScores((size_t)nq * max_results); std::vector<uint8_t> hTies(out_ties ? (size_t)nq * max_results : 0);
-    DOWN(hKeys.data(), s->dFKeys, (size_t)nq * max_results * 8);
-    DOWN(hScores.data(), s->dFScores, (size_t)nq * max_results * 4);
-    if (out_ties) DOWN(hTies.data(), s->dFTies, (size_t)nq * max_results);
+    s->timedFused = true;
+    return INFX_OK;
+}
+
+// result rows -> caller buffers (after the stream is synchronised); rows beyond a query's count stay untouched
+struct FusedResultStage { std::vector<int64_t> k; std::vector<float> sc; std::vector<uint8_t> t; };
+static int32_t fused_download_results(infx_stream* s, uint32_t nq, int32_t max_results, FusedResultStage& R, bool ties, uint32_t* out_counts, uint32_t* out_flags, uint32_t* err) {
+    R.k.resize((size_t)nq * max_results); R.sc.resize((size_t)nq * max_results); R.t.resize(ties ? (size_t)nq * max_results : 0);
+    DOWN(R.k.data(), s->dFKeys, (size_t)nq * max_results * 8);
+    DOWN(R.sc.data(), s->dFScores, (size_t)nq * max_results * 4);
+    if (ties) DOWN(R.t.data(), s->dFTies, (size_t)nq * max_results);
     DOWN(out_counts, s->dFCounts, (size_t)nq * 4);
     if (out_flags) DOWN(out_flags, s->dFFlags, (size_t)nq * 4);
-    DOWN(&err, s->dFErr, 4);
+    DOWN(err, s->dFErr, 4);
+    return INFX_OK;
+}
+static void fused_scatter_results(uint32_t nq, int32_t max_results, const FusedResultStage& R, int64_t* out_keys, float* out_scores, uint8_t* out_ties, const uint32_t* out_counts) {
+    for (uint32_t i = 0; i < nq; i++) {
+        const size_t o = (size_t)i * max_results, c = std::min<size_t>(out_counts[i], (size_t)max_results);
+        std::memcpy(out_keys + o, R.k.data() + o, c * 8); std::memcpy(out_scores + o, R.sc.data() + o, c * 4);
+        if (out_ties) std::memcpy(out_ties + o, R.t.data() + o, c);
+    }
+}
+static void fused_take_metas(infx_stream* s, const std::vector<FusedMeta>& metas) {
+    s->fusedS1 = s->fusedCands = s->fusedTextBytes = 0;
+    for (auto& m : metas) { s->fusedS1 += m.s1Count; s->fusedCands += m.candCount; s->fusedTextBytes += (uint64_t)m.pad0 + ((uint64_t)m.pad1 << 32); }
+}
+
+int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint32_t nterms, const infx_term* terms,
+                          uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq,
+                          uint32_t nlists, const infx_wm_list* lists, uint32_t owned_n, const int32_t* owned,
+                          int32_t depth, int32_t max_results, int32_t want_debug,
+                          int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags) {
+    if (!s || (nd && (!q || (nterms && !terms))) || (nq && (!fq || !cq || !out_keys || !out_scores || !out_counts)) || (nlists && !lists) || (owned_n && !owned))
+        return fail(INFX_EINVAL, "null argument%s");
+    infx_index* ix = s->ix;
+    if (!ix->havePostings || !ix->haveDocs || !ix->d.text) return fail(INFX_EINVAL, "index not uploaded%s");
+    if (ix->nranks > 1 || ix->d.docBase != 0) return fail(INFX_EINVAL, "infx_search_fused needs an unsharded index (sharded engines use infx_shard_*)%s");
+    if (nq == 0) return INFX_OK;
+    { int32_t rc_ = fused_check_queries(ix, nd, nq, fq, cq, nlists, lists, owned_n, depth, max_results); if (rc_) return rc_; }
+    for (uint32_t i = 0; i < nd; i++) if (q[i].depth != depth) return fail(INFX_EINVAL, "all queries of a fused batch share one depth%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    if (nd) { int32_t rc_ = acc_enqueue(s, nd, q, nterms, terms, 0, nullptr); if (rc_) return rc_; }
+    else { HIPCHK(hipEventRecord(s->evA0, s->st)); HIPCHK(hipEventRecord(s->evA1, s->st)); }
+    { int32_t rc_ = fused_enqueue_select(s, nd, depth); if (rc_) return rc_; }
+    { int32_t rc_ = fused_enqueue_prep_stage2(s, 1, nd, (const infx_hit*)s->dHits, (const uint32_t*)s->dHitCount, nq, fq, cq, nlists, lists, owned_n, owned, depth, want_debug); if (rc_) return rc_; }
+    { int32_t rc_ = fused_enqueue_finalize(s, nq, depth, max_results, out_ties != nullptr); if (rc_) return rc_; }
+    uint32_t ovf = 0, err = 0; std::vector<unsigned long long> qbytes(nd); std::vector<SelRule> rules(nd); std::vector<FusedMeta> metas(nq);
+    FusedResultStage R;
+    DOWN(metas.data(), s->dFMeta, (size_t)nq * sizeof(FusedMeta));
+    { int32_t rc_ = fused_download_results(s, nq, max_results, R, out_ties != nullptr, out_counts, out_flags, &err); if (rc_) return rc_; }
     if (nd) { DOWN(&ovf, s->dOverflow, 4); DOWN(qbytes.data(), s->dQBytes, (size_t)nd * 8); DOWN(rules.data(), s->dRules, (size_t)nd * sizeof(SelRule)); }
     SYNC();
     if (ovf) return fail(INFX_ECAPACITY, "candidate arena overflow (bound violated)%s");
     if (err) return fail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)%s");
-    for (uint32_t i = 0; i < nq; i++) {     // rows beyond a query's count stay untouched in the caller's buffers
-        const size_t o = (size_t)i * max_results, c = std::min<size_t>(out_counts[i], (size_t)max_results);
-        std::memcpy(out_keys + o, hKeys.data() + o, c * 8); std::memcpy(out_scores + o, hScores.data() + o, c * 4);
-        if (out_ties) std::memcpy(out_ties + o, hTies.data() + o, c);
-    }
+    fused_scatter_results(nq, max_results, R, out_keys, out_scores, out_ties, out_counts);
     s->lastAlgBytes = 0; for (auto b : qbytes) s->lastAlgBytes += b;
     s->lastCandTotal = 0; for (auto& r : rules) s->lastCandTotal += r.total;
-    s->fusedNq = nq; s->fusedDepth = depth; s->fusedDebug = want_debug != 0;
-    s->fusedS1 = s->fusedCands = s->fusedTextBytes = 0;
-    for (auto& m : metas) { s->fusedS1 += m.s1Count; s->fusedCands += m.candCount; s->fusedTextBytes += (uint64_t)m.pad0 + ((uint64_t)m.pad1 << 32); }
+    fused_take_metas(s, metas);
+    return INFX_OK;
+}
+
+// ---- document-sharded operation: the same device stages with the collectives of SURVEY 8(e) in between (host buffers) ----------
+int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global_counts, int32_t depth, infx_hit* hits_out, uint32_t* hitcount_out) {
+    if (!s || (nd && (!global_counts || !hits_out || !hitcount_out))) return fail(INFX_EINVAL, "null argument%s");
+    if (nd == 0) return INFX_OK;
+    if (nd != s->lastNq) return fail(INFX_EINVAL, "infx_shard_select must follow infx_stage1_accumulate of the same batch%s");
+    infx_index* ix = s->ix;
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    UP(s->dCounts, global_counts, (size_t)nd * INFX_NCLASS * 4);          // the tier rules see the GLOBAL cardinalities (quirk Q11)
+    { int32_t rc_ = fused_enqueue_select(s, nd, depth); if (rc_) return rc_; }
+    std::vector<SelRule> rules(nd);
+    DOWN(hits_out, s->dHits, (size_t)nd * depth * sizeof(infx_hit));
+    DOWN(hitcount_out, s->dHitCount, (size_t)nd * 4);
+    DOWN(rules.data(), s->dRules, (size_t)nd * sizeof(SelRule));
+    SYNC();
+    s->lastCandTotal = 0; for (auto& r : rules) s->lastCandTotal += r.total;
+    return INFX_OK;
+}
+
+int32_t infx_shard_stage2(infx_stream* s, int32_t nshards, uint32_t nd, const infx_hit* all_hits, const uint32_t* all_hitcounts,
+                          uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq, uint32_t nlists, const infx_wm_list* lists,
+                          uint32_t owned_n, const int32_t* owned, int32_t depth, int32_t max_results, int32_t want_debug, infx_cov_out* outs_out) {
+    if (!s || nshards < 1 || (nd && (!all_hits || !all_hitcounts)) || (nq && (!fq || !cq || !outs_out)) || (nlists && !lists) || (owned_n && !owned))
+        return fail(INFX_EINVAL, "null argument%s");
+    infx_index* ix = s->ix;
+    if (!ix->haveDocs || !ix->d.text || !ix->d.docKeyAll) return fail(INFX_EINVAL, "index not uploaded%s");
+    if (nq == 0) return INFX_OK;
+    { int32_t rc_ = fused_check_queries(ix, nd, nq, fq, cq, nlists, lists, owned_n, depth, max_results); if (rc_) return rc_; }
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    const size_t nh = (size_t)nshards * std::max<size_t>(1, nd) * depth;
+    GROW(s->dFHitsAll, s->capFHitsAll, nh * sizeof(infx_hit));
+    GROW(s->dFHcAll, s->capFHcAll, (size_t)nshards * std::max<size_t>(1, nd) * 4);
+    UP(s->dFHitsAll, all_hits, (size_t)nshards * nd * depth * sizeof(infx_hit));
+    UP(s->dFHcAll, all_hitcounts, (size_t)nshards * nd * 4);
+    { int32_t rc_ = fused_enqueue_prep_stage2(s, nshards == 1 ? 1 : nshards, nd, (const infx_hit*)s->dFHitsAll, (const uint32_t*)s->dFHcAll, nq, fq, cq, nlists, lists, owned_n, owned, depth, want_debug); if (rc_) return rc_; }
+    std::vector<FusedMeta> metas(nq);
+    DOWN(metas.data(), s->dFMeta, (size_t)nq * sizeof(FusedMeta));
+    DOWN(outs_out, s->dCovO, (size_t)nq * 2 * depth * sizeof(infx_cov_out));
+    SYNC();
+    fused_take_metas(s, metas);
+    return INFX_OK;
+}
+
+int32_t infx_shard_finalize(infx_stream* s, uint32_t nq, const infx_cov_out* merged_outs, int32_t depth, int32_t max_results,
+                            int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags) {
+    if (!s || (nq && (!merged_outs || !out_keys || !out_scores || !out_counts))) return fail(INFX_EINVAL, "null argument%s");
+    if (nq == 0) return INFX_OK;
+    if (nq != s->fusedNq || depth != s->fusedDepth) return fail(INFX_EINVAL, "infx_shard_finalize must follow infx_shard_stage2 of the same batch%s");
+    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    UP(s->dCovO, merged_outs, (size_t)nq * 2 * depth * sizeof(infx_cov_out));
+    { int32_t rc_ = fused_enqueue_finalize(s, nq, depth, max_results, out_ties != nullptr); if (rc_) return rc_; }
+    uint32_t err = 0; FusedResultStage R;
+    { int32_t rc_ = fused_download_results(s, nq, max_results, R, out_ties != nullptr, out_counts, out_flags, &err); if (rc_) return rc_; }
+    SYNC();
+    if (err) return fail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)%s");
+    fused_scatter_results(nq, max_results, R, out_keys, out_scores, out_ties, out_counts);
+    return INFX_OK;
+}
+
+int32_t infx_upload_doc_keys_all(infx_index* ix, uint32_t total_docs, const int64_t* keys) {
+    if (!ix || (total_docs && !keys)) return fail(INFX_EINVAL, "null argument%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    int64_t* d = nullptr;
+    HIPCHK(dalloc(ix, &d, (size_t)total_docs + 1));
+    if (total_docs) HIPCHK(hipMemcpy(d, keys, (size_t)total_docs * 8, hipMemcpyHostToDevice));
+    ix->d.docKeyAll = d;
     return INFX_OK;
 }
 
