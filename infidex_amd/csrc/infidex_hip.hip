@@ -224,6 +224,13 @@ static int32_t grow(void** p, size_t* cap, size_t need) {
 }
 #define GROW(p, cap, need) do { int32_t rc_ = grow((void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)
 
+// Stage-2 launches: the register budget of the fast variant is selectable for tuning (INFX_S2_WAVES = 2, 4 or 6 waves per SIMD)
+static int s2_waves() { static const int w = [] { const char* e = getenv("INFX_S2_WAVES"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4 || v == 6 || v == 8) ? v : S2_MIN_WAVES; }(); return w; }
+#define S2_GRID (ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st
+#define S2_LAUNCH_FAST(...) do { switch (s2_waves()) { case 2: k_stage2<S2_FASTD, 2><<<S2_GRID>>>(__VA_ARGS__); break; case 6: k_stage2<S2_FASTD, 6><<<S2_GRID>>>(__VA_ARGS__); break; case 8: k_stage2<S2_FASTD, 8><<<S2_GRID>>>(__VA_ARGS__); break; \
+                                                     default: k_stage2<S2_FASTD, 4><<<S2_GRID>>>(__VA_ARGS__); break; } } while (0)
+#define S2_LAUNCH_SLOW(...) k_stage2<S2_MAXD, 4><<<S2_GRID>>>(__VA_ARGS__)
+
 // ---- host <-> device transfers through pinned staging -------------------------------------------------------------------
 // The C ABI takes plain (pageable) host pointers.  Handing those to hipMemcpyAsync makes the runtime pin/unpin the caller's pages
 // per copy, which takes the process-wide address-space lock and stalls every host thread that page-faults meanwhile (observed:
@@ -657,8 +664,10 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     UP(s->dCovQ, q, (size_t)nq * sizeof(infx_cov_query));
     UP(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand));
     HIPCHK(hipEventRecord(s->evC0, s->st));
-    k_stage2<<<(ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st>>>(ix->d, (const infx_cov_query*)s->dCovQ, nq,
-                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0);
+    S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq,
+                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 0);
+    S2_LAUNCH_SLOW(ix->d, (const infx_cov_query*)s->dCovQ, nq,
+                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
     s->timedCov = true;
@@ -761,8 +770,10 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evP1, s->st));
     HIPCHK(hipEventRecord(s->evC0, s->st));
-    k_stage2<<<(ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st>>>(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
-                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1);
+    S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
+                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 0);
+    S2_LAUNCH_SLOW(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
+                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
     s->timedCov = true;
