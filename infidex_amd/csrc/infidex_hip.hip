@@ -14,6 +14,7 @@
 // (quirk Q11) are evaluated from per-doc flags; a range that holds no candidate-generating posting exits before it
 // streams anything else (range-granular WAND skip). Survivors are compacted with wave ballots into a batch arena and
 // k_select picks the top-`depth` per query with an LDS radix select + bitonic sort.
+#include <type_traits>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -57,7 +58,8 @@ struct infx_index {
     bool havePostings = false, haveDocs = false, haveWm = false;
     uint64_t nWmExact = 0, nWmLd1 = 0;
     float avgdl = 0.f;
-    std::vector<uint64_t> hPostOff;   // host copy for capacity bounds / alg-bytes accounting
+    std::vector<uint64_t> hPostOff;   // host copy of the (padded) list starts
+    std::vector<uint64_t> hPostLen;   // true list lengths
     std::vector<int32_t> hDf;
     std::vector<uint64_t> hPsOff;
     int rank = 0, nranks = 1;
@@ -70,6 +72,21 @@ template <class Tp> static hipError_t dalloc(infx_index* ix, Tp** p, size_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Device posting layout: every list starts on a 16-byte boundary and is padded to a multiple of 4 postings with the sentinel doc id
+// 0x7F7F7F7F (beyond any real id).  k_accumulate streams lists with 16-byte loads from an aligned-down address; with this layout the
+// extra elements of a group are either postings of the SAME list outside the block's doc range or sentinels, so a plain range check
+// replaces the per-posting index check.  One thread per posting: find its list (upper bound in the unpadded offsets), copy.
+__global__ void k_pad_lists(const uint64_t* __restrict__ offs, const uint64_t* __restrict__ offs2, uint32_t T, uint64_t P,
+                            const int32_t* __restrict__ inDoc, const uint8_t* __restrict__ inW, int32_t* __restrict__ outDoc, uint8_t* __restrict__ outW) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    uint64_t lo = 0, hi = (uint64_t)T + 1;                      // first index with offs[idx] > i
+    while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (offs[m] <= i) lo = m + 1; else hi = m; }
+    const uint64_t t = lo - 1;
+    const uint64_t dst = offs2[t] + (i - offs[t]);
+    outDoc[dst] = inDoc[i]; outW[dst] = inW[i];
+}
+
 // skip table build: one thread per (skipped term, range boundary)
 __global__ void k_build_skip(const uint64_t* postOff, const int32_t* postDoc, const uint32_t* skipTerms, uint32_t nSkip,
                              uint32_t* skipTbl, int nRanges, int rshift) {
@@ -366,10 +383,24 @@ int32_t infx_upload_postings(infx_index* ix, uint32_t T, const uint64_t* offs, c
     HIPCHK(hipSetDevice(ix->cfg.device));
     uint64_t P = offs[T];
     uint64_t* dOff = nullptr; int32_t* dDoc = nullptr; uint8_t* dW = nullptr;
-    HIPCHK(dalloc(ix, &dOff, (size_t)T + 1)); HIPCHK(dalloc(ix, &dDoc, (size_t)P + 4)); HIPCHK(dalloc(ix, &dW, (size_t)P));   // +4: k_accumulate reads whole 16-byte groups
-    HIPCHK(hipMemcpy(dOff, offs, ((size_t)T + 1) * 8, hipMemcpyHostToDevice));
-    if (P) { HIPCHK(hipMemcpy(dDoc, doc_ids, (size_t)P * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dW, tf, (size_t)P, hipMemcpyHostToDevice)); }
-    ix->hPostOff.assign(offs, offs + T + 1); ix->hDf.assign(df, df + T);
+    // padded layout (k_pad_lists): list t lives at [off2[t], off2[t] + len_t), the rest of its 4-aligned slot holds sentinels
+    std::vector<uint64_t> off2((size_t)T + 1); off2[0] = 0;
+    for (uint32_t t = 0; t < T; t++) off2[t + 1] = off2[t] + ((offs[t + 1] - offs[t] + 3) & ~(uint64_t)3);
+    const uint64_t P2 = off2[T];
+    HIPCHK(dalloc(ix, &dOff, (size_t)T + 1)); HIPCHK(dalloc(ix, &dDoc, (size_t)P2 + 4)); HIPCHK(dalloc(ix, &dW, (size_t)P2 + 4));
+    HIPCHK(hipMemcpy(dOff, off2.data(), ((size_t)T + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dDoc, 0x7F, ((size_t)P2 + 4) * 4)); HIPCHK(hipMemset(dW, 0, (size_t)P2 + 4));
+    if (P) {
+        uint64_t* tOff = nullptr; int32_t* tDoc = nullptr; uint8_t* tW = nullptr;
+        HIPCHK(hipMalloc((void**)&tOff, ((size_t)T + 1) * 8)); HIPCHK(hipMalloc((void**)&tDoc, (size_t)P * 4)); HIPCHK(hipMalloc((void**)&tW, (size_t)P));
+        HIPCHK(hipMemcpy(tOff, offs, ((size_t)T + 1) * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(tDoc, doc_ids, (size_t)P * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(tW, tf, (size_t)P, hipMemcpyHostToDevice));
+        k_pad_lists<<<(unsigned)((P + 255) / 256), 256>>>(tOff, dOff, T, P, tDoc, tW, dDoc, dW);
+        HIPCHK(hipDeviceSynchronize());
+        hipFree(tOff); hipFree(tDoc); hipFree(tW);
+    }
+    ix->hPostOff = off2; ix->hDf.assign(df, df + T);
+    ix->hPostLen.resize(T); for (uint32_t t = 0; t < T; t++) ix->hPostLen[t] = offs[t + 1] - offs[t];
     // Range skip tables (nRanges+1 offsets per list): a workgroup finds a list's slice inside its doc range with one lookup
     // instead of two ~log2(df)-step binary searches whose dependent L2 round trips every (query, range) workgroup would pay.
     // HBM is plentiful, so every list of >= 64 postings gets one as long as the tables stay below 2^31 entries (8 GiB);
@@ -493,12 +524,12 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
             DevTerm D{}; D.idf = tm.idf; D.role = tm.role; D.rank = tm.rank; D.pad = 0;
             if (tm.term_id >= 0) {
                 if (tm.term_id >= ix->d.T) return fail(INFX_EINVAL, "term id out of range%s");
-                D.begin = ix->hPostOff[tm.term_id]; D.end = ix->hPostOff[tm.term_id + 1]; D.isVirtual = 0;
+                D.begin = ix->hPostOff[tm.term_id]; D.end = D.begin + ix->hPostLen[tm.term_id]; D.isVirtual = 0;
                 dt.push_back(D); termOfEntry.push_back(tm.term_id);
                 if (gen) qb += D.end - D.begin;
             } else if (tm.reserved == 2) {     // union built on the device by the last infx_union_build: extra_off = its index
                 if (tm.extra_off >= s->unionCount.size()) return fail(INFX_EINVAL, "virtual term refers to a union that was not built%s");
-                D.begin = s->unionBase[tm.extra_off]; D.end = s->unionBase[tm.extra_off + 1]; D.isVirtual = 4 | 2;
+                D.begin = s->unionBase[tm.extra_off]; D.end = D.begin + s->unionCount[tm.extra_off]; D.isVirtual = 4 | 2;
                 D.skip = (uint32_t)((uint64_t)tm.extra_off * (ix->d.nRanges + 1));     // k_union's per-range offsets are its skip table
                 dt.push_back(D); termOfEntry.push_back(-1);
                 if (gen) qb += D.end - D.begin;
@@ -509,7 +540,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
                 for (uint32_t m = 0; m < tm.extra_len; m++) {
                     int32_t mt = extra_docs[tm.extra_off + m];
                     if (mt < 0 || mt >= ix->d.T) return fail(INFX_EINVAL, "member term id out of range%s");
-                    DevTerm M = D; M.begin = ix->hPostOff[mt]; M.end = ix->hPostOff[mt + 1]; M.isVirtual = 2; M.pad = (uint8_t)group;
+                    DevTerm M = D; M.begin = ix->hPostOff[mt]; M.end = M.begin + ix->hPostLen[mt]; M.isVirtual = 2; M.pad = (uint8_t)group;
                     dt.push_back(M); termOfEntry.push_back(mt);
                     if (gen) qb += M.end - M.begin;
                 }
@@ -1008,8 +1039,9 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     SYNC();
     s->unionCount.assign(counts_out, counts_out + nv);
     s->unionBase.assign((size_t)nv + 1, 0);
-    for (uint32_t v = 0; v < nv; v++) s->unionBase[v + 1] = s->unionBase[v] + counts_out[v];
+    for (uint32_t v = 0; v < nv; v++) s->unionBase[v + 1] = s->unionBase[v] + ((counts_out[v] + 3u) & ~3u);     // 16-byte aligned, sentinel-padded like the index lists
     GROW(s->dUDocs, s->capUDocs, ((size_t)s->unionBase[nv] + 4) * 4);
+    HIPCHK(hipMemsetAsync(s->dUDocs, 0x7F, ((size_t)s->unionBase[nv] + 4) * 4, s->st));
     UP(s->dUBase, s->unionBase.data(), ((size_t)nv + 1) * 8);
     launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, (const unsigned long long*)s->dUBase, (int32_t*)s->dUDocs);
     HIPCHK(hipGetLastError());
