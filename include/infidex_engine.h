@@ -94,6 +94,7 @@ int32_t infx_engine_index_stats(infx_engine* e, int64_t* n_docs, int64_t* n_term
 int32_t infx_engine_export_index(infx_engine* e, int32_t* df, uint64_t* post_off, int32_t* post_doc, uint8_t* post_w, float* doc_len);
 int32_t infx_engine_term_text(infx_engine* e, int32_t t, uint16_t* out, int32_t cap);
 int32_t infx_engine_match_ld1(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int32_t cap);
+int32_t infx_engine_match_ld1_forward(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int32_t cap);
 int32_t infx_engine_plan(infx_engine* e, const uint16_t* q, int32_t len, int32_t depth, int32_t* term_ids, int32_t* dfs, float* idfs,
                          uint8_t* roles, uint8_t* ranks, int32_t cap, int32_t* meta5, int32_t* flags);
 int64_t infx_engine_wordmatcher(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int64_t cap);

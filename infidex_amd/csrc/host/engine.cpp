@@ -806,6 +806,12 @@ int32_t infx_engine_match_ld1(infx_engine* e, const uint16_t* q, int32_t len, in
     return c;
 }
 // Stage-1 plan of one query (no GPU needed): returns number of terms; mode/prefix_set/n_and/df_s1/df_s2 in meta[5]
+int32_t infx_engine_match_ld1_forward(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int32_t cap) {   // the literal trie walk (test cross-check)
+    if (!e) return -1;
+    std::vector<int> m; int c = match_ld1_forward(e->ix, uview((const u16*)q, (size_t)len), m, cap);
+    for (size_t i = 0; i < m.size() && (int32_t)i < cap; i++) out[i] = m[i];
+    return c;
+}
 int32_t infx_engine_plan(infx_engine* e, const uint16_t* q, int32_t len, int32_t depth, int32_t* term_ids, int32_t* dfs, float* idfs,
                          uint8_t* roles, uint8_t* ranks, int32_t cap, int32_t* meta, int32_t* flags) {
     if (!e) return -1;

@@ -241,6 +241,8 @@ struct HostIndex {
     std::vector<TrieNode> trie;
     // contiguous, label-sorted out-edges of every node (scanning a node's labels touches 1-3 cache lines, not one per child)
     std::vector<uint32_t> edgeStart; std::vector<u16> edgeLabel; std::vector<uint32_t> edgeChild;
+    // trie over the REVERSED terms (suffix trie), CSR edges only: LD1 matching walks it anchored at the term end (query.h match_ld1)
+    std::vector<uint32_t> rEdgeStart; std::vector<u16> rEdgeLabel; std::vector<uint32_t> rEdgeChild; std::vector<int32_t> rTerm;
     // prefix DocSets
     Csr prefixAll;                  // temp
     KeyTable prefixKeys; std::vector<uint32_t> prefixPop; std::vector<int32_t> prefixSetId;   // per prefix key: population, uploaded set id or -1
@@ -460,6 +462,43 @@ inline void build_index(const DocSource& src, HostIndex& ix) {
         for (size_t v = 0; v < nn; v++) { uint32_t c = 0; for (uint32_t k = ix.trie[v].firstChild; k; k = ix.trie[k].nextSibling) c++; ix.edgeStart[v + 1] = ix.edgeStart[v] + c; }
         ix.edgeLabel.resize(ix.edgeStart[nn]); ix.edgeChild.resize(ix.edgeStart[nn]);
         for (size_t v = 0; v < nn; v++) { uint32_t p = ix.edgeStart[v]; for (uint32_t k = ix.trie[v].firstChild; k; k = ix.trie[k].nextSibling) { ix.edgeLabel[p] = ix.trie[k].label; ix.edgeChild[p] = k; p++; } }
+    }
+    {   // reversed-term trie
+        std::vector<u16> arena; std::vector<uint64_t> ao(T + 1, 0);
+        for (size_t i = 0; i < T; i++) ao[i + 1] = ao[i] + ix.terms.keys.key((uint32_t)i).size();
+        arena.resize(ao[T]);
+        parallel_for((int64_t)T, threads, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; i++) { uview k = ix.terms.keys.key((uint32_t)i); u16* d = arena.data() + ao[i]; for (size_t c = 0; c < k.size(); c++) d[c] = k[k.size() - 1 - c]; }
+        });
+        auto rkey = [&](uint32_t id) { return uview(arena.data() + ao[id], (size_t)(ao[id + 1] - ao[id])); };
+        std::vector<uint32_t> order(T);
+        for (size_t i = 0; i < T; i++) order[i] = (uint32_t)i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rkey(a) < rkey(b); });
+        struct N { u16 label; int32_t term; uint32_t firstChild, nextSibling; };
+        std::vector<N> tr; tr.push_back({0, -1, 0, 0});
+        std::vector<uint32_t> path{0}, lastChild{0};
+        uview prev;
+        for (uint32_t id : order) {
+            uview s2 = rkey(id);
+            size_t lcp = 0, mx = std::min(prev.size(), s2.size());
+            while (lcp < mx && prev[lcp] == s2[lcp]) lcp++;
+            path.resize(lcp + 1); lastChild.resize(lcp + 1);
+            for (size_t dpt = lcp; dpt < s2.size(); dpt++) {
+                uint32_t nn = (uint32_t)tr.size();
+                tr.push_back({s2[dpt], -1, 0, 0});
+                uint32_t parent = path[dpt];
+                if (tr[parent].firstChild == 0) tr[parent].firstChild = nn; else tr[lastChild[dpt]].nextSibling = nn;
+                lastChild[dpt] = nn;
+                path.push_back(nn); lastChild.push_back(0);
+            }
+            tr[path[s2.size()]].term = (int32_t)id;
+            prev = s2;
+        }
+        size_t nn = tr.size();
+        ix.rTerm.resize(nn); ix.rEdgeStart.assign(nn + 1, 0);
+        for (size_t v = 0; v < nn; v++) { ix.rTerm[v] = tr[v].term; uint32_t c = 0; for (uint32_t k = tr[v].firstChild; k; k = tr[k].nextSibling) c++; ix.rEdgeStart[v + 1] = ix.rEdgeStart[v] + c; }
+        ix.rEdgeLabel.resize(ix.rEdgeStart[nn]); ix.rEdgeChild.resize(ix.rEdgeStart[nn]);
+        for (size_t v = 0; v < nn; v++) { uint32_t p2 = ix.rEdgeStart[v]; for (uint32_t k = tr[v].firstChild; k; k = tr[k].nextSibling) { ix.rEdgeLabel[p2] = tr[k].label; ix.rEdgeChild[p2] = k; p2++; } }
     }
     // ---- prefix DocSets: keep the lists prefix precedence can accept, counts for the rest --------------------------------
     {

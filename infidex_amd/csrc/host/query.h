@@ -60,7 +60,7 @@ template <class T, class Cmp> inline void bcl_sort(std::vector<T>& v, Cmp cmp) {
 // A subtree is skipped when min_i(D[i][j] + max(0, j-1-i)) > 1: completing the pattern from row i needs m-i more text
 // characters but at most m+1-j remain below depth m+1, and a fresh start (row 0) deeper than column 2 costs >= 2.
 // When every live row has no error budget left, only children whose label continues an exact match are visited.
-inline int match_ld1(const HostIndex& ix, uview q, std::vector<int>& out, int cap = 1024) {
+inline int match_ld1_forward(const HostIndex& ix, uview q, std::vector<int>& out, int cap = 1024) {
     out.clear();
     const int m = (int)q.size();
     if (m == 0 || m > 64 || ix.trie.empty()) return 0;
@@ -108,6 +108,60 @@ inline int match_ld1(const HostIndex& ix, uview q, std::vector<int>& out, int ca
         if (any1) push_children(f.node, j + 1, nullptr, 0);
         else if (nwant) push_children(f.node, j + 1, want, nwant);
     }
+    return count;
+}
+
+// The same set through the reversed-term trie.  match_ld1_forward accepts a term t (|t| <= m+1) iff some SUFFIX s of t has
+// LD(q, s) <= 1 (the search variant's free start); |s| >= m-1, so at most two leading "junk" characters precede s.  Walking the
+// reversed trie anchors the match at the term END: an ordinary LD<=1 automaton over reverse(q) visits O(m * fan-out) nodes
+// (instead of every 1-2 character prefix of the vocabulary), and each accepted node is extended by the <= 2 junk characters.
+// Results are returned in the forward trie's pre-order (= lexicographic order of the terms), first `cap` kept, like the forward walk.
+inline int match_ld1(const HostIndex& ix, uview q, std::vector<int>& out, int cap = 1024) {
+    out.clear();
+    const int m = (int)q.size();
+    if (m == 0 || m > 64 || ix.rEdgeStart.empty()) return 0;
+    struct St { uint32_t node; int16_t i, d; uint8_t e; };
+    St st[1024]; int sp = 0; std::vector<St> big;
+    auto push = [&](uint32_t node, int i, int e, int d) { St x{node, (int16_t)i, (int16_t)d, (uint8_t)e}; if (sp < 1024) st[sp++] = x; else big.push_back(x); };
+    auto pop = [&](St& x) { if (!big.empty()) { x = big.back(); big.pop_back(); return true; } if (sp == 0) return false; x = st[--sp]; return true; };
+    std::vector<int> found;
+    // accepted node at depth d: every terminal descendant within g <= m+1-d further levels (g <= 2) is a match
+    auto accept = [&](uint32_t node, int d) {
+        uint32_t fr[2][0]; (void)fr;
+        struct E { uint32_t node; int g; };
+        E es[256]; int ep = 0; std::vector<E> eb;
+        auto epush = [&](uint32_t n2, int g) { if (ep < 256) es[ep++] = {n2, g}; else eb.push_back({n2, g}); };
+        epush(node, 0);
+        for (;;) {
+            E x; if (!eb.empty()) { x = eb.back(); eb.pop_back(); } else if (ep > 0) x = es[--ep]; else break;
+            if (ix.rTerm[x.node] >= 0) found.push_back(ix.rTerm[x.node]);
+            if (d + x.g >= m + 1) continue;
+            for (uint32_t k = ix.rEdgeStart[x.node]; k < ix.rEdgeStart[x.node + 1]; k++) epush(ix.rEdgeChild[k], x.g + 1);
+        }
+    };
+    push(0, 0, 0, 0);
+    St x;
+    while (pop(x)) {
+        const int i = x.i, e = x.e, d = x.d;
+        // pattern fully consumed (possibly after deleting its last characters within the budget) -> accepted at this node
+        if (i == m) accept(x.node, d);
+        else if (e == 0 && i == m - 1) accept(x.node, d);            // delete the last pattern character
+        if (i < m && e == 0) push(x.node, i + 1, 1, d);              // deletion of rq[i] (no text consumed); its acceptance is handled when popped
+        if (d >= m + 1) continue;                                     // terms longer than m+1 cannot match
+        const u16 want = i < m ? q[m - 1 - i] : 0;
+        for (uint32_t k = ix.rEdgeStart[x.node]; k < ix.rEdgeStart[x.node + 1]; k++) {
+            const u16 lb = ix.rEdgeLabel[k]; const uint32_t ch = ix.rEdgeChild[k];
+            if (i < m && lb == want) push(ch, i + 1, e, d + 1);                       // match
+            if (e == 0) {
+                if (i < m && lb != want) push(ch, i + 1, 1, d + 1);                   // substitution
+                push(ch, i, 1, d + 1);                                                  // insertion (extra text character)
+            }
+        }
+    }
+    std::sort(found.begin(), found.end()); found.erase(std::unique(found.begin(), found.end()), found.end());
+    std::sort(found.begin(), found.end(), [&](int a, int c) { return ix.terms.keys.key((uint32_t)a) < ix.terms.keys.key((uint32_t)c); });
+    const int count = (int)found.size();
+    for (int k = 0; k < count && k < cap; k++) out.push_back(found[k]);
     return count;
 }
 

@@ -222,6 +222,11 @@ class SearchEngine:
         n = self.L.infx_engine_term_text(self.h, int(t), _p(buf, C.c_uint16), 256)
         return buf[:max(n, 0)].tobytes().decode("utf-16-le", errors="surrogatepass")
 
+    def match_ld1_forward(self, q, cap=1024):
+        a = _u16(q); out = np.zeros(cap, np.int32)
+        c = self.L.infx_engine_match_ld1_forward(self.h, _p(a, C.c_uint16), len(a), _p(out, C.c_int32), cap)
+        return c, out[:min(c, cap)].copy()
+
     def match_ld1(self, q, cap=1024):
         a = _u16(q); out = np.zeros(cap, np.int32)
         c = self.L.infx_engine_match_ld1(self.h, _p(a, C.c_uint16), len(a), _p(out, C.c_int32), cap)

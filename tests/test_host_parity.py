@@ -129,3 +129,30 @@ def test_normalizer_tables_agree():
     for lower in (False, True):
         assert E.normalize(chars, lower) == O.normalize(chars, lower)
     assert E.normalize("a \t\n  b", True) == "a b"
+
+
+def test_ld1_reverse_trie_equals_forward_walk():
+    """match_ld1 (anchored walk of the reversed-term trie) returns exactly what the literal forward walk of
+    FstIndex.MatchWithinEditDistance1 (FstIndex.cs:202-351, restated as match_ld1_forward) returns, in the same order."""
+    import random
+    from tools.synth import Synth
+    s = Synth(4, docs=60000)
+    arena, offs = s.docs()
+    e = SearchEngine.create_default(device=-1); e.index_flat(None, arena, offs, s.field_weights)
+    qa, qo = s.queries(400, qseed=77)
+    words = sorted({w for q in Synth.texts(qa, qo) for w in q.split()})
+    rng = random.Random(5)
+    probes = list(words)
+    for w in words[:300]:           # extra mutations: deletions, insertions, substitutions, transposed ends, prefixes with junk
+        if len(w) >= 3:
+            i = rng.randrange(len(w)); probes.append(w[:i] + w[i + 1:])
+            probes.append(w[:i] + rng.choice("abcxyz") + w[i:])
+            probes.append(w[:i] + rng.choice("abcxyz") + w[i + 1:])
+            probes.append(rng.choice("qz") + w); probes.append(w[1:]); probes.append(w[2:] if len(w) > 4 else w)
+    n_nonempty = 0
+    for w in probes:
+        c1, m1 = e.match_ld1(w, 1024)
+        c2, m2 = e.match_ld1_forward(w, 1024)
+        assert c1 == c2 and m1.tolist() == m2.tolist(), (w, c1, c2, m1[:8].tolist(), m2[:8].tolist())
+        n_nonempty += c1 > 0
+    assert n_nonempty > len(probes) // 4
