@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--range-docs", type=int, default=0)
     ap.add_argument("--build-threads", type=int, default=0)
-    ap.add_argument("--sessions", type=int, default=3, help="batches in flight (host threads, one engine session each)")
+    ap.add_argument("--sessions", type=int, default=2, help="batches in flight (host threads, one engine session each)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent full-index replicas instead of document shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU-baseline sample (0 = auto, ~10-30 s)")
@@ -217,7 +217,8 @@ def main():
         "roofline": {"kernel": "k_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": acc_ms,
-                     "streamed_bytes_per_launch": streamed, "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
+                     "streamed_bytes_per_launch": streamed, "stage1_candidates_per_launch": float(np.mean([t["stage1_candidates"] for t in roof])),
+                     "stage2_rows_per_launch": float(np.mean([t["stage2_candidates"] for t in roof])), "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
                      "other_kernels_ms": {kk: float(np.mean([t[kk + "_ms"] for t in roof])) for kk in ("k_select", "k_prep2", "k_stage2", "k_finalize")},
                      "note": "achieved = SURVEY 8(d) algorithmic bytes / k_accumulate duration (HIP events, uncontended launch); ranges without "
                              "candidates are skipped, so fewer bytes are streamed than the algorithm nominally reads"},

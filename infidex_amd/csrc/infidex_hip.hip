@@ -230,6 +230,7 @@ struct infx_stream {
     float msAcc = 0, msSel = 0, msCov = 0;
     uint64_t lastAlgBytes = 0, lastCandTotal = 0;
     bool timedAcc = false, timedSel = false, timedCov = false;
+    void* dStats = nullptr;      // k_accumulate profiling counters (INFX_ACC_SKIP=8)
 };
 
 static int32_t grow(void** p, size_t* cap, size_t need) {
@@ -313,7 +314,9 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
     size_t lds = (size_t)(R / 32) * 6 + 8 + (size_t)cap * (12 + (useGrp ? 1 : 0)) + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
     uint64_t blocks = (uint64_t)nq * s->ix->d.nRanges;
     k_accumulate<R><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, cap, useGrp, dbgSkip);
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, cap, useGrp, dbgSkip, (unsigned long long*)s->dStats);
+    if (dbgSkip & 8) { unsigned long long h[4] = {0, 0, 0, 0}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 32, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 32);
+        fprintf(stderr, "[infx] k_accumulate stats: %llu blocks with candidates of %llu, %.2f rounds/block, %.1f candidates/block\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0); }
 }
 
 extern "C" {
@@ -480,6 +483,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1, &s->evP0, &s->evP1, &s->evF0, &s->evF1};
     for (auto e : ev) HIPCHK(hipEventCreate(e));
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
+    HIPCHK(hipMalloc((void**)&s->dStats, 32)); HIPCHK(hipMemset(s->dStats, 0, 32));
     *out = s; return INFX_OK;
 }
 void infx_stream_destroy(infx_stream* s) {
