@@ -47,9 +47,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("INFX_FORCE_SHARDED") == "1"      # exercise the sharded / RCCL code path with a single rank
+    if world > 1 or force_sharded:
         import torch
         import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("INFX_DIST_BACKEND", "nccl")     # "gloo" lets two ranks share one GPU when testing the sharded flow
         local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
@@ -90,7 +93,7 @@ def main():
 
     # ---- product: index + upload ---------------------------------------------------------------------------------------
     t0 = time.time()
-    sharded = world > 1 and not args.replicas
+    sharded = (world > 1 or force_sharded) and not args.replicas
     if sharded:
         # north-star layout: the 10 M-doc index is document-sharded over the GPUs, every rank answers the SAME query stream,
         # per-shard top-k merged by an RCCL all-gather (infidex_amd/sharded.py)

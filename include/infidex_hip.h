@@ -220,6 +220,8 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
  *   infx_shard_stage2   : merge of the nshards lists, candidate assembly, Stage 2 on the rows whose document this shard holds
  *                         (all other rows are zero)                                  -> all-reduce(sum) of outs (nq x 2*depth x 12 B)
  *   infx_shard_finalize : final ordering / truncation from the merged rows (identical on every rank).
+ * The exchange buffers (hits_out / hitcount_out, all_hits / all_hitcounts, outs_out, merged_outs) may be host OR device memory: device
+ * pointers (e.g. the tensors a torch.distributed / RCCL collective works on) are copied device-to-device, nothing crosses PCIe.
  * Every shard needs the GLOBAL DocumentKey table (infx_upload_doc_keys_all) and the WordMatcher lists (global ids). */
 int32_t infx_upload_doc_keys_all(infx_index* idx, uint32_t total_docs, const int64_t* keys);
 int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global_counts, int32_t depth, infx_hit* hits_out, uint32_t* hitcount_out);

@@ -739,6 +739,39 @@ int32_t infx_session_phase3(infx_session* S, int32_t W, const infx_hit* all_hits
     B.t4 = now_ms();
     return INFX_OK;
 }
+// Variants whose exchange buffers are caller memory on the host OR the device (e.g. the tensors an RCCL collective works on):
+// nothing is staged through the session's host vectors.
+int32_t infx_session_phase2x(infx_session* S, const uint32_t* global_counts, void* hits, void* hitcounts) {
+    if (!S || !global_counts || !hits || !hitcounts) return efail(INFX_EINVAL, "null");
+    Batch& B = *S->batch;
+    if (B.nd) {
+        int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, (infx_hit*)hits, (uint32_t*)hitcounts);
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+        infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
+        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates);
+        uint64_t ab = 0;
+        for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)S->e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
+        S->algBytes = ab + S->s1Candidates * 4ull + (uint64_t)B.nd * B.depth * 12ull;
+    }
+    B.t2 = now_ms();
+    return INFX_OK;
+}
+int32_t infx_session_phase3x(infx_session* S, int32_t W, const void* all_hits, const void* all_counts, int32_t max_results, int32_t enable_coverage, void* outs) {
+    if (!S || W < 1 || max_results < 1 || !outs) return efail(INFX_EINVAL, "bad arguments");
+    infx_engine* e = S->e; Batch& B = *S->batch;
+    B.maxResults = max_results;
+    FusedIn FI; int32_t rc = build_fused_inputs(e, S, max_results, enable_coverage, FI); if (rc) return rc;
+    B.t3 = now_ms();
+    if (B.nq) {
+        rc = infx_shard_stage2(S->stream, W, B.nd, (const infx_hit*)all_hits, (const uint32_t*)all_counts, B.nq, FI.fq.data(), FI.cq.data(), (uint32_t)FI.lists.size(), FI.lists.data(),
+                               (uint32_t)FI.owned.size(), FI.owned.data(), B.depth, max_results, 0, (infx_cov_out*)outs);
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+        float ms5[5] = {0, 0, 0, 0, 0}; infx_last_fused_timings(S->stream, ms5); S->msPrep2 = ms5[2]; S->msCov = ms5[3];
+        infx_last_fused_stats(S->stream, nullptr, &S->s2Candidates, &S->s2TextBytes);
+    }
+    B.t4 = now_ms();
+    return INFX_OK;
+}
 int32_t infx_session_outs(infx_session* S, int32_t* outs3) {   // ncand x 3 int32 words; zeros for candidates another shard owns
     if (!S || !outs3) return efail(INFX_EINVAL, "null");
     static_assert(sizeof(infx_cov_out) == 12, "infx_cov_out is exchanged as 3 int32 words");

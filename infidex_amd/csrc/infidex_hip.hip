@@ -288,6 +288,28 @@ static int32_t down(infx_stream* s, void* dstHost, const void* srcDev, size_t by
     s->pendingOut.push_back({dstHost, p, bytes});
     return INFX_OK;
 }
+// Exchange buffers of the sharded stage API may live on the device (e.g. torch CUDA tensors handed to RCCL): those are copied
+// device-to-device on the stream instead of being staged through the pinned arena.
+static bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // plain pageable host memory
+    return a.type == hipMemoryTypeDevice;
+}
+static int32_t upx(infx_stream* s, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return INFX_OK;
+    if (!is_device_ptr(src)) return up(s, dst, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->st)); s->unsynced = true;
+    return INFX_OK;
+}
+static int32_t downx(infx_stream* s, void* dst, const void* srcDev, size_t bytes) {
+    if (!bytes) return INFX_OK;
+    if (!is_device_ptr(dst)) return down(s, dst, srcDev, bytes);
+    HIPCHK(hipMemcpyAsync(dst, srcDev, bytes, hipMemcpyDeviceToDevice, s->st)); s->unsynced = true;
+    return INFX_OK;
+}
+#define UPX(dst, src, n) do { int32_t rc_ = upx(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
+#define DOWNX(dst, src, n) do { int32_t rc_ = downx(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
 #define UP(dst, src, n) do { int32_t rc_ = up(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
 #define DOWN(dst, src, n) do { int32_t rc_ = down(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
 #define SYNC() do { int32_t rc_ = stream_sync(s); if (rc_) return rc_; } while (0)
@@ -909,8 +931,8 @@ int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global
     UP(s->dCounts, global_counts, (size_t)nd * INFX_NCLASS * 4);          // the tier rules see the GLOBAL cardinalities (quirk Q11)
     { int32_t rc_ = fused_enqueue_select(s, nd, depth); if (rc_) return rc_; }
     std::vector<SelRule> rules(nd);
-    DOWN(hits_out, s->dHits, (size_t)nd * depth * sizeof(infx_hit));
-    DOWN(hitcount_out, s->dHitCount, (size_t)nd * 4);
+    DOWNX(hits_out, s->dHits, (size_t)nd * depth * sizeof(infx_hit));
+    DOWNX(hitcount_out, s->dHitCount, (size_t)nd * 4);
     DOWN(rules.data(), s->dRules, (size_t)nd * sizeof(SelRule));
     SYNC();
     s->lastCandTotal = 0; for (auto& r : rules) s->lastCandTotal += r.total;
@@ -931,12 +953,12 @@ int32_t infx_shard_stage2(infx_stream* s, int32_t nshards, uint32_t nd, const in
     const size_t nh = (size_t)nshards * std::max<size_t>(1, nd) * depth;
     GROW(s->dFHitsAll, s->capFHitsAll, nh * sizeof(infx_hit));
     GROW(s->dFHcAll, s->capFHcAll, (size_t)nshards * std::max<size_t>(1, nd) * 4);
-    UP(s->dFHitsAll, all_hits, (size_t)nshards * nd * depth * sizeof(infx_hit));
-    UP(s->dFHcAll, all_hitcounts, (size_t)nshards * nd * 4);
+    UPX(s->dFHitsAll, all_hits, (size_t)nshards * nd * depth * sizeof(infx_hit));
+    UPX(s->dFHcAll, all_hitcounts, (size_t)nshards * nd * 4);
     { int32_t rc_ = fused_enqueue_prep_stage2(s, nshards == 1 ? 1 : nshards, nd, (const infx_hit*)s->dFHitsAll, (const uint32_t*)s->dFHcAll, nq, fq, cq, nlists, lists, owned_n, owned, depth, want_debug); if (rc_) return rc_; }
     std::vector<FusedMeta> metas(nq);
     DOWN(metas.data(), s->dFMeta, (size_t)nq * sizeof(FusedMeta));
-    DOWN(outs_out, s->dCovO, (size_t)nq * 2 * depth * sizeof(infx_cov_out));
+    DOWNX(outs_out, s->dCovO, (size_t)nq * 2 * depth * sizeof(infx_cov_out));
     SYNC();
     fused_take_metas(s, metas);
     return INFX_OK;
@@ -949,7 +971,7 @@ int32_t infx_shard_finalize(infx_stream* s, uint32_t nq, const infx_cov_out* mer
     if (nq != s->fusedNq || depth != s->fusedDepth) return fail(INFX_EINVAL, "infx_shard_finalize must follow infx_shard_stage2 of the same batch%s");
     HIPCHK(hipSetDevice(s->ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
-    UP(s->dCovO, merged_outs, (size_t)nq * 2 * depth * sizeof(infx_cov_out));
+    UPX(s->dCovO, merged_outs, (size_t)nq * 2 * depth * sizeof(infx_cov_out));
     { int32_t rc_ = fused_enqueue_finalize(s, nq, depth, max_results, out_ties != nullptr); if (rc_) return rc_; }
     uint32_t err = 0; FusedResultStage R;
     { int32_t rc_ = fused_download_results(s, nq, max_results, R, out_ties != nullptr, out_counts, out_flags, &err); if (rc_) return rc_; }

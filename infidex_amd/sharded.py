@@ -110,6 +110,27 @@ class ShardSession:
             self.e._check(self.L.infx_session_outs(self.s.h, _p(outs, C.c_int32)))
         return outs[:self.ncand]
 
+    # ---- device-resident exchange buffers (torch CUDA tensors; RCCL works on them in place) ----
+    def phase2_dev(self, global_counts, hits_t, hc_t):
+        gc = np.ascontiguousarray(global_counts, np.uint32)
+        if gc.size == 0:
+            gc = np.zeros((1, INFX_NCLASS), np.uint32)
+        self.e._check(self.L.infx_session_phase2x(self.s.h, _p(gc, C.c_uint32), C.c_void_p(hits_t.data_ptr()), C.c_void_p(hc_t.data_ptr())))
+
+    def phase3_dev(self, all_hits_t, all_hc_t, outs_t, max_results, enable_coverage=True):
+        W = all_hits_t.shape[0]
+        self.max_results = max_results
+        self.e._check(self.L.infx_session_phase3x(self.s.h, W, C.c_void_p(all_hits_t.data_ptr()), C.c_void_p(all_hc_t.data_ptr()), max_results, int(enable_coverage),
+                                                  C.c_void_p(outs_t.data_ptr())))
+
+    def phase4_dev(self, merged_t):
+        nq, mr = self.nq, self.max_results
+        keys = np.full((nq, mr), -1, np.int64); scores = np.zeros((nq, mr), np.float32)
+        ties = np.zeros((nq, mr), np.uint8); counts = np.zeros(nq, np.uint32); flags = np.zeros(nq, np.uint32)
+        self.e._check(self.L.infx_session_phase4(self.s.h, C.c_void_p(merged_t.data_ptr()), _p(keys, C.c_int64), _p(scores, C.c_float), _p(ties, C.c_uint8),
+                                                 _p(counts, C.c_uint32), _p(flags, C.c_uint32)))
+        return keys, scores, ties, counts, flags
+
     def phase4(self, merged_outs):
         nq, mr = self.nq, self.max_results
         keys = np.full((nq, mr), -1, np.int64); scores = np.zeros((nq, mr), np.float32)
@@ -135,6 +156,21 @@ class ShardedSearcher:
         guc = c.allreduce_sum_i32(uc) if uc.size else uc                                          # Exchange 1b: df of new fuzzy unions
         counts = self.sess.phase1(guc)
         gcounts = c.allreduce_sum_i32(counts) if counts.size else counts                       # Exchange 1
+        if c.device.type == "cuda" and c.dist.get_backend() == "nccl":
+            # RCCL path: the hit lists and the Stage-2 rows stay in HBM; the collectives run on the tensors the kernels wrote
+            torch = c.torch; s = self.sess; nd = max(s.nd, 1); nq = s.nq
+            hits_t = torch.zeros((nd, depth, 2), dtype=torch.int32, device=c.device); hc_t = torch.zeros(nd, dtype=torch.int32, device=c.device)
+            s.phase2_dev(gcounts, hits_t, hc_t)
+            all_hits_t = torch.empty((c.world, nd, depth, 2), dtype=torch.int32, device=c.device)
+            all_hc_t = torch.empty((c.world, nd), dtype=torch.int32, device=c.device)
+            c.dist.all_gather_into_tensor(all_hits_t, hits_t)                                     # Exchange 2 (RCCL all-gather of top-k over xGMI)
+            c.dist.all_gather_into_tensor(all_hc_t, hc_t)
+            outs_t = torch.zeros((max(nq, 1) * 2 * depth, 3), dtype=torch.int32, device=c.device)
+            torch.cuda.current_stream().synchronize()
+            s.phase3_dev(all_hits_t, all_hc_t, outs_t, max_results, enable_coverage)
+            c.dist.all_reduce(outs_t, op=c.dist.ReduceOp.SUM)                                     # disjoint Stage-2 rows
+            torch.cuda.current_stream().synchronize()
+            return s.phase4_dev(outs_t)
         hits, hc = self.sess.phase2(gcounts)
         all_hits = c.allgather(hits) if hits.size else hits.reshape((c.world,) + hits.shape)      # Exchange 2 (RCCL all-gather of top-k)
         all_hc = c.allgather(hc) if hc.size else hc.reshape((c.world,) + hc.shape)
@@ -144,6 +180,30 @@ class ShardedSearcher:
 
     def last_timings(self):
         return self.sess.s.last_timings()
+
+
+def simulate_shards_dev(sessions: Sequence[ShardSession], arena, offs, max_results=10, depth=500, enable_coverage=True, device="cuda:0"):
+    """simulate_shards with the exchange buffers as torch CUDA tensors (the RCCL code path minus the collectives, which are
+    replaced by torch.stack / sum on the same device)."""
+    import torch
+    ucs = [s.phase0(arena, offs, depth) for s in sessions]
+    guc = np.sum(np.stack(ucs).astype(np.uint64), axis=0).astype(np.uint32) if ucs[0].size else ucs[0]
+    counts = [s.phase1(guc) for s in sessions]
+    g = np.sum(np.stack(counts).astype(np.uint64), axis=0).astype(np.uint32)
+    nd = max(sessions[0].nd, 1); nq = sessions[0].nq
+    hits, hcs = [], []
+    for s in sessions:
+        h = torch.zeros((nd, depth, 2), dtype=torch.int32, device=device); c = torch.zeros(nd, dtype=torch.int32, device=device)
+        s.phase2_dev(g, h, c); hits.append(h); hcs.append(c)
+    all_hits = torch.stack(hits).contiguous(); all_hc = torch.stack(hcs).contiguous()
+    outs = []
+    for s in sessions:
+        o = torch.zeros((max(nq, 1) * 2 * depth, 3), dtype=torch.int32, device=device)
+        torch.cuda.synchronize()
+        s.phase3_dev(all_hits, all_hc, o, max_results, enable_coverage); outs.append(o)
+    merged = torch.stack(outs).sum(dim=0, dtype=torch.int32).contiguous()
+    torch.cuda.synchronize()
+    return [s.phase4_dev(merged) for s in sessions]
 
 
 def simulate_shards(sessions: Sequence[ShardSession], arena, offs, max_results=10, depth=500, enable_coverage=True):

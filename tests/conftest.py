@@ -9,3 +9,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """torch ships its own HIP runtime; when a test also uses torch CUDA tensors (the RCCL exchange-buffer path of the sharded
+    phases) torch must initialise the GPU before libinfidex_hip.so pulls in the system runtime, exactly as bench.py does."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass

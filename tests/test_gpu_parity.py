@@ -188,7 +188,8 @@ def test_sharded_equals_unsharded():
     qs = Synth.texts(qa, qo) + ["qu", "zzzzqq", "the"]
     a2, o2 = pack_texts(qs)
     rk, rs, rt, rc, rf = ref.search_packed(a2, o2, 10)
-    res = simulate_shards(sess, a2, o2, 10)
+    from infidex_amd.sharded import simulate_shards_dev
+    res = simulate_shards(sess, a2, o2, 10) + simulate_shards_dev(sess, a2, o2, 10)      # host buffers, then device tensors (RCCL path)
     for (k, sc, t, c, f) in res:
         assert np.array_equal(c, rc)
         assert np.array_equal(k, rk)
