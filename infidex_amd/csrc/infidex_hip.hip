@@ -48,6 +48,7 @@ struct DevIndex {
     const int32_t* wmExact;    // WordMatcher exact-word doc lists (infx_upload_wordmatcher), global ids
     const int32_t* wmLd1;      // WordMatcher symmetric-delete doc lists
     const int64_t* docKeyAll;  // DocumentKey by GLOBAL internal id (== docKey when unsharded)
+    int packed;                // 1: postDoc entries are (doc << 8) | tf (shards below 2^24 - 1 documents), 0: plain doc ids + postW
     const uint64_t* psOff; const int32_t* psDocs; uint32_t nSets;
 };
 
@@ -77,19 +78,19 @@ template <class Tp> static hipError_t dalloc(infx_index* ix, Tp** p, size_t n) {
 // extra elements of a group are either postings of the SAME list outside the block's doc range or sentinels, so a plain range check
 // replaces the per-posting index check.  One thread per posting: find its list (upper bound in the unpadded offsets), copy.
 __global__ void k_pad_lists(const uint64_t* __restrict__ offs, const uint64_t* __restrict__ offs2, uint32_t T, uint64_t P,
-                            const int32_t* __restrict__ inDoc, const uint8_t* __restrict__ inW, int32_t* __restrict__ outDoc, uint8_t* __restrict__ outW) {
+                            const int32_t* __restrict__ inDoc, const uint8_t* __restrict__ inW, int32_t* __restrict__ outDoc, uint8_t* __restrict__ outW, int packed) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     uint64_t lo = 0, hi = (uint64_t)T + 1;                      // first index with offs[idx] > i
     while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (offs[m] <= i) lo = m + 1; else hi = m; }
     const uint64_t t = lo - 1;
     const uint64_t dst = offs2[t] + (i - offs[t]);
-    outDoc[dst] = inDoc[i]; outW[dst] = inW[i];
+    outDoc[dst] = packed ? (int32_t)(((uint32_t)inDoc[i] << 8) | inW[i]) : inDoc[i]; outW[dst] = inW[i];
 }
 
 // skip table build: one thread per (skipped term, range boundary)
 __global__ void k_build_skip(const uint64_t* postOff, const int32_t* postDoc, const uint32_t* skipTerms, uint32_t nSkip,
-                             uint32_t* skipTbl, int nRanges, int rshift) {
+                             uint32_t* skipTbl, int nRanges, int rshift, int packed) {
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t per = (uint64_t)nRanges + 1;
     if (gid >= (uint64_t)nSkip * per) return;
@@ -98,7 +99,7 @@ __global__ void k_build_skip(const uint64_t* postOff, const int32_t* postDoc, co
     uint64_t lo = postOff[t], hi = postOff[t + 1];
     int64_t target = (int64_t)r << rshift;
     uint64_t a = lo, b = hi;
-    while (a < b) { uint64_t m = (a + b) >> 1; if ((int64_t)postDoc[m] < target) a = m + 1; else b = m; }
+    while (a < b) { uint64_t m = (a + b) >> 1; if ((int64_t)(packed ? (int32_t)((uint32_t)postDoc[m] >> 8) : postDoc[m]) < target) a = m + 1; else b = m; }
     skipTbl[(uint64_t)s * per + r] = (uint32_t)(a - lo);
 }
 
@@ -138,6 +139,12 @@ __device__ __forceinline__ uint64_t rfl_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// posting lists of a packed index hold (doc << 8) | tf; sentinels are 0xFFFFFFFF
+__device__ __forceinline__ int32_t post_doc(int32_t v, int packed) { return packed ? (int32_t)((uint32_t)v >> 8) : v; }
+__device__ __forceinline__ uint64_t lower_bound_post(const int32_t* a, uint64_t lo, uint64_t hi, int32_t target, int packed) {
+    while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (post_doc(a[m], packed) < target) lo = m + 1; else hi = m; }
+    return lo;
+}
 __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t lo, uint64_t hi, int32_t target) {
     while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (a[m] < target) lo = m + 1; else hi = m; }
     return lo;
@@ -414,13 +421,16 @@ int32_t infx_upload_postings(infx_index* ix, uint32_t T, const uint64_t* offs, c
     const uint64_t P2 = off2[T];
     HIPCHK(dalloc(ix, &dOff, (size_t)T + 1)); HIPCHK(dalloc(ix, &dDoc, (size_t)P2 + 4)); HIPCHK(dalloc(ix, &dW, (size_t)P2 + 4));
     HIPCHK(hipMemcpy(dOff, off2.data(), ((size_t)T + 1) * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(dDoc, 0x7F, ((size_t)P2 + 4) * 4)); HIPCHK(hipMemset(dW, 0, (size_t)P2 + 4));
+    // packed postings: (doc << 8) | tf in one word — the tf of a candidate posting needs no second (gather) access and a posting costs 4 B
+    // instead of 5 B of traffic; possible while shard-local doc ids stay below 2^24 - 1 (sentinel 0xFFFFFFFF decodes to doc 2^24 - 1)
+    ix->d.packed = ((uint64_t)ix->d.N < 0xFFFFFEull && !getenv("INFX_UNPACKED")) ? 1 : 0;
+    HIPCHK(hipMemset(dDoc, ix->d.packed ? 0xFF : 0x7F, ((size_t)P2 + 4) * 4)); HIPCHK(hipMemset(dW, 0, (size_t)P2 + 4));
     if (P) {
         uint64_t* tOff = nullptr; int32_t* tDoc = nullptr; uint8_t* tW = nullptr;
         HIPCHK(hipMalloc((void**)&tOff, ((size_t)T + 1) * 8)); HIPCHK(hipMalloc((void**)&tDoc, (size_t)P * 4)); HIPCHK(hipMalloc((void**)&tW, (size_t)P));
         HIPCHK(hipMemcpy(tOff, offs, ((size_t)T + 1) * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(tDoc, doc_ids, (size_t)P * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(tW, tf, (size_t)P, hipMemcpyHostToDevice));
-        k_pad_lists<<<(unsigned)((P + 255) / 256), 256>>>(tOff, dOff, T, P, tDoc, tW, dDoc, dW);
+        k_pad_lists<<<(unsigned)((P + 255) / 256), 256>>>(tOff, dOff, T, P, tDoc, tW, dDoc, dW, ix->d.packed);
         HIPCHK(hipDeviceSynchronize());
         hipFree(tOff); hipFree(tDoc); hipFree(tW);
     }
@@ -450,7 +460,7 @@ int32_t infx_upload_postings(infx_index* ix, uint32_t T, const uint64_t* offs, c
         HIPCHK(hipMalloc((void**)&dSkipTerms, skipTerms.size() * 4));
         HIPCHK(hipMemcpy(dSkipTerms, skipTerms.data(), skipTerms.size() * 4, hipMemcpyHostToDevice));
         uint64_t tot = skipTerms.size() * per;
-        k_build_skip<<<(unsigned)((tot + 255) / 256), 256>>>(dOff, dDoc, dSkipTerms, (uint32_t)skipTerms.size(), dSkipTbl, nR, ix->d.rshift);
+        k_build_skip<<<(unsigned)((tot + 255) / 256), 256>>>(dOff, dDoc, dSkipTerms, (uint32_t)skipTerms.size(), dSkipTbl, nR, ix->d.rshift, ix->d.packed);
         HIPCHK(hipDeviceSynchronize());
         hipFree(dSkipTerms);
     }
@@ -480,7 +490,7 @@ int32_t infx_upload_prefix_docsets(infx_index* ix, uint32_t nsets, const uint64_
             HIPCHK(hipMalloc((void**)&dSets, sets.size() * 4));
             HIPCHK(hipMemcpy(dSets, sets.data(), sets.size() * 4, hipMemcpyHostToDevice));
             uint64_t n = sets.size() * per;
-            k_build_skip<<<(unsigned)((n + 255) / 256), 256>>>(dOff, dDocs, dSets, (uint32_t)sets.size(), dPsTbl, nR, ix->d.rshift);
+            k_build_skip<<<(unsigned)((n + 255) / 256), 256>>>(dOff, dDocs, dSets, (uint32_t)sets.size(), dPsTbl, nR, ix->d.rshift, 0);
             HIPCHK(hipDeviceSynchronize());
             hipFree(dSets);
         }
