@@ -205,8 +205,8 @@ struct infx_stream {
     hipStream_t st = nullptr;
     hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1;
     // fused pipeline workspaces
-    void *dFQ = nullptr, *dFLists = nullptr, *dFOwned = nullptr, *dFS1 = nullptr, *dFMeta = nullptr, *dFQueries = nullptr, *dFKeys = nullptr, *dFScores = nullptr, *dFTies = nullptr, *dFCounts = nullptr, *dFFlags = nullptr, *dFErr = nullptr, *dFHitsAll = nullptr, *dFHcAll = nullptr;
-    size_t capFQ = 0, capFLists = 0, capFOwned = 0, capFS1 = 0, capFMeta = 0, capFQueries = 0, capFKeys = 0, capFScores = 0, capFTies = 0, capFCounts = 0, capFFlags = 0, capFErr = 0, capFHitsAll = 0, capFHcAll = 0;
+    void *dFQ = nullptr, *dFLists = nullptr, *dFOwned = nullptr, *dFS1 = nullptr, *dFMeta = nullptr, *dFQueries = nullptr, *dFKeys = nullptr, *dFScores = nullptr, *dFTies = nullptr, *dFCounts = nullptr, *dFFlags = nullptr, *dFErr = nullptr, *dFHitsAll = nullptr, *dFHcAll = nullptr, *dFPairs = nullptr;
+    size_t capFQ = 0, capFLists = 0, capFOwned = 0, capFS1 = 0, capFMeta = 0, capFQueries = 0, capFKeys = 0, capFScores = 0, capFTies = 0, capFCounts = 0, capFFlags = 0, capFErr = 0, capFHitsAll = 0, capFHcAll = 0, capFPairs = 0;
     uint64_t fusedS1 = 0, fusedCands = 0, fusedTextBytes = 0;
     uint32_t fusedNq = 0; int fusedDepth = 0; bool fusedDebug = false, timedFused = false; float msFused[5] = {0, 0, 0, 0, 0};
     // device workspaces (grown on demand)
@@ -523,7 +523,7 @@ void infx_stream_destroy(infx_stream* s) {
     hipSetDevice(s->ix->cfg.device);
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
-                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll};
+                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs};
     for (void* p : ps) if (p) hipFree(p);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
@@ -732,9 +732,9 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     UP(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand));
     HIPCHK(hipEventRecord(s->evC0, s->st));
     S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq,
-                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 0);
+                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 0, nullptr);
     S2_LAUNCH_SLOW(ix->d, (const infx_cov_query*)s->dCovQ, nq,
-                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 1);
+                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 1, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
     s->timedCov = true;
@@ -819,6 +819,7 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
     GROW(s->dCovQ, s->capCovQ, (size_t)nq * sizeof(infx_cov_query));
     GROW(s->dCovC, s->capCovC, (size_t)ncand * sizeof(infx_cov_cand));
     GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
+    GROW(s->dFPairs, s->capFPairs, (size_t)ncand * 4);
     if (want_debug) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
     UP(s->dFQ, fq, (size_t)nq * sizeof(infx_fused_query));
     UP(s->dFLists, lists, (size_t)nlists * sizeof(infx_wm_list));
@@ -832,15 +833,15 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_prep2<<<nq, P2_THREADS, lds, s->st>>>(ix->d, dHitsAll, dHcAll, depth, W, (int)nd, (int)Dall, (const infx_fused_query*)s->dFQ,
                                                  (const infx_wm_list*)s->dFLists, (const int32_t*)s->dFOwned, depth, (int)Dp,
-                                                 (infx_hit*)s->dFS1, (infx_cov_cand*)s->dCovC, (FusedMeta*)s->dFMeta);
+                                                 (infx_hit*)s->dFS1, (infx_cov_cand*)s->dCovC, (int32_t*)s->dFPairs, (FusedMeta*)s->dFMeta);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evP1, s->st));
     HIPCHK(hipEventRecord(s->evC0, s->st));
     S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
-                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 0);
+                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 0, (const int32_t*)s->dFPairs);
     S2_LAUNCH_SLOW(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
-                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 1);
+                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 1, (const int32_t*)s->dFPairs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
     s->timedCov = true;
