@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--range-docs", type=int, default=0)
     ap.add_argument("--build-threads", type=int, default=0)
-    ap.add_argument("--sessions", type=int, default=2, help="batches in flight (host threads, one engine session each)")
+    ap.add_argument("--sessions", type=int, default=3, help="batches in flight (host threads, one engine session each)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent full-index replicas instead of document shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU-baseline sample (0 = auto, ~10-30 s)")
