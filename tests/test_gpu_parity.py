@@ -195,3 +195,39 @@ def test_sharded_equals_unsharded():
         assert np.array_equal(k, rk)
         assert np.array_equal(sc, rs)      # bit-identical scores: same kernels, same arithmetic, only the doc ranges differ
         assert np.array_equal(t, rt)
+
+
+def test_long_documents_take_the_retry_launch():
+    """Documents with more than 32 tokens are re-scored by the second k_stage2 launch (192-token tables); results must still match
+    the oracle row for row.  Documents beyond 192 tokens are outside the Stage-2 envelope and fail loudly."""
+    import random
+    rng = random.Random(3)
+    vocab = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet", "kilo", "lima", "mike",
+             "november", "oscar", "papa", "quebec", "romeo", "sierra", "tango", "uniform", "victor", "whiskey", "xray", "yankee", "zulu"]
+    docs = []
+    for i in range(300):
+        n = rng.choice([5, 12, 31, 32, 33, 40, 64, 100, 150, 190])
+        docs.append((i, " ".join(rng.choice(vocab) + (str(rng.randrange(30)) if rng.random() < 0.3 else "") for _ in range(n))))
+    e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+    o = O.OracleEngine.create_default(); o.index(docs)
+    qs = ["alpha bravo", "charlie delta echo", "foxtrt golf", "hotel india12", "zulu", "november oscar papa quebec", "xray yankee", "kilo lima mik"]
+    st = compare_batch(e, o, qs, 10)
+    assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, st
+    from infidex_amd.engine import InfidexError
+    e2 = gpu_engine(); e2.index_documents([Document(0, " ".join(vocab[i % 26] + str(i) for i in range(260))), Document(1, "alpha bravo")])
+    with pytest.raises(InfidexError):
+        e2.search_batch(["alpha bravo"], 5)
+
+
+def test_depth_and_result_count_variants(ten):
+    e, o = ten
+    qs = ["the fox", "batman", "quick", "city", "new york city"]
+    for k, depth in ((1, 500), (3, 500), (10, 4), (2, 2), (10, 1)):
+        res = e.search_batch(qs, k, depth)
+        for q, r in zip(qs, res):
+            ro = o.search(q, k, depth)
+            assert [x.document_id for x in r.records] == ro["keys"], (q, k, depth)
+    # blank / whitespace / too-short queries inside a batch do not disturb their neighbours
+    res = e.search_batch(["", "   ", "a", "batman", "qick fux"], 10)
+    assert [len(r.records) for r in res[:3]] == [0, 0, 0]
+    assert [x.document_id for x in res[3].records][0] == 6 and [x.document_id for x in res[4].records] == [5, 1]
