@@ -231,3 +231,13 @@ def test_depth_and_result_count_variants(ten):
     res = e.search_batch(["", "   ", "a", "batman", "qick fux"], 10)
     assert [len(r.records) for r in res[:3]] == [0, 0, 0]
     assert [x.document_id for x in res[3].records][0] == 6 and [x.document_id for x in res[4].records] == [5, 1]
+
+
+def test_batches_without_any_index_term():
+    """A batch whose queries hit no index term at all (nd == 0): no Stage-1 launch, coverage still runs on WordMatcher candidates."""
+    e = gpu_engine(); e.index_documents([Document(k, t) for k, t in TEN_DOCS])
+    o = O.OracleEngine.create_default(); o.index(TEN_DOCS)
+    qs = ["zzzzqqq", "xq", "", "wwwwvvvv kkkkjjjj"]
+    res = e.search_batch(qs, 10)
+    for q, r in zip(qs, res):
+        assert [x.document_id for x in r.records] == o.search(q, 10)["keys"], q
