@@ -128,14 +128,18 @@ def main():
         sync()
         tim, lat, results = [], [], []
         t_start = time.time()
-        for s in range(args.warmup, nsteps):
-            ts = time.time()
-            keys, scores, ties, counts, flags = searcher.search_packed(batches[s][0], batches[s][1], k, 500)
-            lat.append((time.time() - ts) * 1000.0)
+        stamps = []
+        # planner thread: phase 0 of the next batch overlaps the collective phases of the current one (sharded.py search_stream)
+        def lockstep(bs):
+            for a_, o_ in bs:
+                t0_ = time.time(); r_ = searcher.search_packed(a_, o_, k, 500); stamps.append((t0_, time.time())); yield r_
+        stream = lockstep(batches[args.warmup:nsteps]) if os.environ.get("INFX_SHARD_LOCKSTEP") == "1" else searcher.search_stream(batches[args.warmup:nsteps], k, 500, stamps=stamps)
+        for keys, scores, ties, counts, flags in stream:
             tim.append(searcher.last_timings())
             results.append((keys, counts))
+        lat = [(b - a) * 1000.0 for a, b in stamps]
         first_keys = (results[0][0].copy(), results[0][1].copy())
-        nsess = 1
+        nsess = 2
         sessions = None
     else:
         nsess = max(1, min(args.sessions, args.steps))
@@ -260,7 +264,12 @@ def main():
                                "index_build_s": orc_box["build_s"], "identical_topk_sets": f"{same}/{sample}"}
         out["speedup_vs_cpu_baseline"] = qps / (sample / secs)
     if rank == 0:
-        print(json.dumps(out))
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)        # RCCL's start-up banner sits in the C stdio buffer: flush it BEFORE the result line
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -27,6 +27,12 @@ class TorchComm:
         import torch
         self.torch = torch
         self.dist = dist
+        # torch's CPU ops would otherwise wake an OpenMP team as wide as the host (256 threads here) that spins after every tiny
+        # copy: under a container CPU quota that burns the budget and the whole process is throttled for tens of milliseconds
+        try:
+            torch.set_num_threads(1)
+        except Exception:
+            pass
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.device = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
@@ -144,42 +150,93 @@ class ShardSession:
 
 
 class ShardedSearcher:
-    """One rank of a document-sharded deployment. All ranks must call search_packed with the same batch."""
+    """One rank of a document-sharded deployment. All ranks must call search_packed / search_stream with the same batches."""
 
     def __init__(self, engine: SearchEngine, comm: TorchComm):
-        self.sess = ShardSession(engine)
+        self.sessions = [ShardSession(engine), ShardSession(engine)]
+        self.sess = self.sessions[0]
         self.comm = comm
+        self.last = self.sess
 
     def search_packed(self, arena, offs, max_results=10, depth=500, enable_coverage=True):
+        s = self.sessions[0]
+        uc = s.phase0(arena, offs, depth)
+        return self._finish(s, uc, max_results, depth, enable_coverage)
+
+    def search_stream(self, batches, max_results=10, depth=500, enable_coverage=True, stamps=None):
+        """Pipelined stream of batches [(arena, offs), ...]: a planner thread runs phase 0 of batch i+1 (text preparation, LD1
+        expansion, k_union — host work and kernels on the OTHER session's stream, no collective) while this thread drives the
+        collective phases of batch i.  Collectives are issued by this thread only, in batch order, so their order is identical on
+        every rank.  Yields the results in order; stamps (optional list) receives (t_plan_start, t_done) per batch."""
+        import queue
+        import threading
+        import time
+        free = [threading.Semaphore(1), threading.Semaphore(1)]
+        q = queue.Queue(maxsize=2)
+
+        def planner():
+            for i, (a, o) in enumerate(batches):
+                j = i % 2
+                free[j].acquire()
+                t0 = time.time()
+                try:
+                    q.put((j, self.sessions[j].phase0(a, o, depth), t0, None))
+                except Exception as ex:      # surfaced by the consumer
+                    q.put((j, None, t0, ex))
+                    return
+
+        th = threading.Thread(target=planner, daemon=True)
+        th.start()
+        for _ in range(len(batches)):
+            j, uc, t0, ex = q.get()
+            if ex is not None:
+                raise ex
+            res = self._finish(self.sessions[j], uc, max_results, depth, enable_coverage)
+            if stamps is not None:
+                stamps.append((t0, time.time()))
+            free[j].release()
+            yield res
+        th.join()
+
+    def _finish(self, s, uc, max_results, depth, enable_coverage):
+        import os, time
         c = self.comm
-        uc = self.sess.phase0(arena, offs, depth)
+        self.last = s
+        dbg = os.environ.get("INFX_DEBUG") is not None
+        T = [time.time()]
+        def mark():
+            if dbg: T.append(time.time())
         guc = c.allreduce_sum_i32(uc) if uc.size else uc                                          # Exchange 1b: df of new fuzzy unions
-        counts = self.sess.phase1(guc)
+        mark(); counts = s.phase1(guc); mark()
         gcounts = c.allreduce_sum_i32(counts) if counts.size else counts                       # Exchange 1
         if c.device.type == "cuda" and c.dist.get_backend() == "nccl":
             # RCCL path: the hit lists and the Stage-2 rows stay in HBM; the collectives run on the tensors the kernels wrote
-            torch = c.torch; s = self.sess; nd = max(s.nd, 1); nq = s.nq
+            torch = c.torch; nd = max(s.nd, 1); nq = s.nq
             hits_t = torch.zeros((nd, depth, 2), dtype=torch.int32, device=c.device); hc_t = torch.zeros(nd, dtype=torch.int32, device=c.device)
-            s.phase2_dev(gcounts, hits_t, hc_t)
+            mark(); s.phase2_dev(gcounts, hits_t, hc_t); mark()
             all_hits_t = torch.empty((c.world, nd, depth, 2), dtype=torch.int32, device=c.device)
             all_hc_t = torch.empty((c.world, nd), dtype=torch.int32, device=c.device)
             c.dist.all_gather_into_tensor(all_hits_t, hits_t)                                     # Exchange 2 (RCCL all-gather of top-k over xGMI)
             c.dist.all_gather_into_tensor(all_hc_t, hc_t)
             outs_t = torch.zeros((max(nq, 1) * 2 * depth, 3), dtype=torch.int32, device=c.device)
             torch.cuda.current_stream().synchronize()
-            s.phase3_dev(all_hits_t, all_hc_t, outs_t, max_results, enable_coverage)
+            mark(); s.phase3_dev(all_hits_t, all_hc_t, outs_t, max_results, enable_coverage); mark()
             c.dist.all_reduce(outs_t, op=c.dist.ReduceOp.SUM)                                     # disjoint Stage-2 rows
             torch.cuda.current_stream().synchronize()
-            return s.phase4_dev(outs_t)
-        hits, hc = self.sess.phase2(gcounts)
-        all_hits = c.allgather(hits) if hits.size else hits.reshape((c.world,) + hits.shape)      # Exchange 2 (RCCL all-gather of top-k)
+            mark(); r = s.phase4_dev(outs_t); mark()
+            if dbg and c.rank == 0:
+                import sys
+                print("[infx-shard] ms: allreduce-uc %.2f phase1 %.2f allreduce-counts+alloc %.2f phase2 %.2f allgather %.2f phase3 %.2f allreduce-rows %.2f phase4 %.2f" % tuple((T[i + 1] - T[i]) * 1e3 for i in range(8)), file=sys.stderr)
+            return r
+        hits, hc = s.phase2(gcounts)
+        all_hits = c.allgather(hits) if hits.size else hits.reshape((c.world,) + hits.shape)      # Exchange 2 (all-gather of top-k)
         all_hc = c.allgather(hc) if hc.size else hc.reshape((c.world,) + hc.shape)
-        outs = self.sess.phase3(all_hits, all_hc, max_results, enable_coverage)
+        outs = s.phase3(all_hits, all_hc, max_results, enable_coverage)
         merged = c.allreduce_sum_i32(outs) if outs.size else outs                              # disjoint Stage-2 records
-        return self.sess.phase4(merged)
+        return s.phase4(merged)
 
     def last_timings(self):
-        return self.sess.s.last_timings()
+        return self.last.s.last_timings()
 
 
 def simulate_shards_dev(sessions: Sequence[ShardSession], arena, offs, max_results=10, depth=500, enable_coverage=True, device="cuda:0"):
