@@ -65,9 +65,26 @@ def main():
     from infidex_amd import SearchEngine, Session, build as _build
     _build.build()
 
+    def quota_cpus():      # the same rule as infx_engine_effective_cpus (affinity mask and cgroup CPU quota), before the library is loaded
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, -(-int(q) // int(per))))
+        except Exception:
+            try:
+                q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0 and per > 0:
+                    n = min(n, max(1, -(-q // per)))
+            except Exception:
+                pass
+        return max(1, n)
+    if world > 1 and "INFX_THREADS" not in os.environ:
+        # one process per GPU shares the host: size every process's planner pool to its share of the CPUs
+        os.environ["INFX_THREADS"] = str(max(1, quota_cpus() // world))
     from infidex_amd.engine import load_library
     ncpu = int(load_library().infx_engine_effective_cpus())     # hardware threads capped by affinity and the cgroup CPU quota
-    bthreads = args.build_threads or max(1, min(64, ncpu // max(1, world)))
+    bthreads = args.build_threads or max(1, min(64, ncpu if "INFX_THREADS" in os.environ else ncpu // max(1, world)))
     full = CONFIGS[args.config]["docs"]
     syn = Synth(args.config, docs=(None if args.docs == full else args.docs), threads=bthreads)
     k = syn.cfg["k"]

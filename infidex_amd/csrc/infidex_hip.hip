@@ -203,7 +203,7 @@ __host__ __device__ static inline SelRule make_rule(const infx_query& Q, const u
 struct infx_stream {
     infx_index* ix;
     hipStream_t st = nullptr;
-    hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1;
+    hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1, evSync;
     // fused pipeline workspaces
     void *dFQ = nullptr, *dFLists = nullptr, *dFOwned = nullptr, *dFS1 = nullptr, *dFMeta = nullptr, *dFQueries = nullptr, *dFKeys = nullptr, *dFScores = nullptr, *dFTies = nullptr, *dFCounts = nullptr, *dFFlags = nullptr, *dFErr = nullptr, *dFHitsAll = nullptr, *dFHcAll = nullptr, *dFPairs = nullptr;
     size_t capFQ = 0, capFLists = 0, capFOwned = 0, capFS1 = 0, capFMeta = 0, capFQueries = 0, capFKeys = 0, capFScores = 0, capFTies = 0, capFCounts = 0, capFFlags = 0, capFErr = 0, capFHitsAll = 0, capFHcAll = 0, capFPairs = 0;
@@ -271,7 +271,10 @@ static void* pin_take(infx_stream* s, size_t bytes) {
     return b;
 }
 static int32_t stream_sync(infx_stream* s) {
-    HIPCHK(hipStreamSynchronize(s->st));
+    // blocking wait (interrupt-driven) instead of hipStreamSynchronize's busy poll: a waiting host thread must not burn a core of a
+    // CPU-quota-limited container while the planner pool of another session (or another rank's process) needs it
+    HIPCHK(hipEventRecord(s->evSync, s->st));
+    HIPCHK(hipEventSynchronize(s->evSync));
     for (auto& d : s->pendingOut) std::memcpy(d.dst, d.src, d.bytes);
     s->pendingOut.clear(); s->unsynced = false;
     return INFX_OK;
@@ -514,6 +517,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
     hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1, &s->evP0, &s->evP1, &s->evF0, &s->evF1};
     for (auto e : ev) HIPCHK(hipEventCreate(e));
+    HIPCHK(hipEventCreateWithFlags(&s->evSync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
     HIPCHK(hipMalloc((void**)&s->dStats, 32)); HIPCHK(hipMemset(s->dStats, 0, 32));
     *out = s; return INFX_OK;
@@ -529,6 +533,7 @@ void infx_stream_destroy(infx_stream* s) {
     for (auto& c : s->pins) hipHostFree(c.base);
     hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1, s->evP0, s->evP1, s->evF0, s->evF1};
     for (auto e : ev) hipEventDestroy(e);
+    hipEventDestroy(s->evSync);
     if (s->st) hipStreamDestroy(s->st);
     delete s;
 }
