@@ -110,3 +110,36 @@ def test_oracle_sample_at_scale(corpus):
         if got == r["keys"]:
             assert np.allclose(scores[i, :len(got)], np.asarray(r["scores"], np.float32), rtol=0, atol=2.0 ** -6 + 1e-6), q
     assert differ <= 3, differ                                            # exact-tie cut-off cases only
+
+
+def test_host_phase_implementation_equals_device_pipeline(tmp_path):
+    """INFX_PHASED=1 routes a single-GPU engine through the stage-wise C ABI (infx_stage1_accumulate / _select, infx_stage2_batch) with the
+    host implementation of tier rules, candidate assembly and final ordering.  It must agree bit for bit with the device pipeline."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np
+from infidex_amd import SearchEngine
+from infidex_amd.engine import pack_texts
+from tools.synth import Synth
+s = Synth(2, docs=20000); arena, offs = s.docs()
+e = SearchEngine.create_default(device=0); e.index_flat(None, arena, offs, s.field_weights)
+qa, qo = s.queries(300, qseed=9, fuzz=0.3)
+a, o = pack_texts(Synth.texts(qa, qo) + ["qu", "", "zzzzqq"])
+k, sc, t, c, f = e.search_packed(a, o, 10)
+np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f)
+'''
+    outs = []
+    for phased in ("0", "1"):
+        env = dict(os.environ); env.pop("INFX_PHASED", None)
+        if phased == "1":
+            env["INFX_PHASED"] = "1"
+        env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = str(tmp_path / f"r{phased}.npz")
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=env, timeout=600)
+        outs.append(np.load(path))
+    a, b = outs
+    assert np.array_equal(a["c"], b["c"]) and np.array_equal(a["f"], b["f"])
+    for i in range(len(a["c"])):
+        n = int(a["c"][i])
+        assert np.array_equal(a["k"][i, :n], b["k"][i, :n]) and np.array_equal(a["sc"][i, :n], b["sc"][i, :n]) and np.array_equal(a["t"][i, :n], b["t"][i, :n])
