@@ -66,6 +66,9 @@ int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, floa
  *   phase3 (merge to the global top-depth, Stage-2 prep, k_stage2 on the OWNED candidates)
  *          -> all-reduce(sum) of infx_session_outs (ncand x 3 int32; every candidate is scored by exactly one shard)
  *   phase4 (final ordering / truncation). */
+/* SynonymMap.AddSynonym (Synonyms/SynonymMap.cs:33-62), before infx_engine_index_documents: index text, query text and coverage text are
+ * canonicalised with the map (UTF-16 terms). */
+int32_t infx_engine_add_synonym(infx_engine* e, const uint16_t* a, int32_t la, const uint16_t* b, int32_t lb);
 int32_t infx_engine_set_shard(infx_engine* e, int32_t rank, int32_t nranks);      /* before infx_engine_index_documents */
 int32_t infx_engine_shard_info(infx_engine* e, int32_t* doc_base, int32_t* num_docs);
 int32_t infx_engine_default_session(infx_engine* e, infx_session** out);

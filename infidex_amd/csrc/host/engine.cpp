@@ -661,6 +661,12 @@ int32_t infx_engine_session_search_batch(infx_session* S, uint32_t nq, const uin
     return search_batch_impl(S->e, S, nq, q_arena, q_offs, max_results, depth, enable_coverage, out_keys, out_scores, out_ties, out_counts, out_flags);
 }
 // ---- sharded operation: phases with the collectives in between (infidex_amd/sharded.py) ----
+int32_t infx_engine_add_synonym(infx_engine* e, const uint16_t* a, int32_t la, const uint16_t* b, int32_t lb) {
+    if (!e || !a || !b || la < 0 || lb < 0) return efail(INFX_EINVAL, "bad arguments");
+    if (e->indexed) return efail(INFX_EINVAL, "synonyms must be added before IndexDocuments");
+    e->ix.cfg.syn.add(uview((const u16*)a, (size_t)la), uview((const u16*)b, (size_t)lb));
+    return INFX_OK;
+}
 int32_t infx_engine_set_shard(infx_engine* e, int32_t rank, int32_t nranks) {
     if (!e || nranks < 1 || rank < 0 || rank >= nranks) return efail(INFX_EINVAL, "bad shard arguments");
     if (e->indexed) return efail(INFX_EINVAL, "set the shard before IndexDocuments");

@@ -225,6 +225,7 @@ struct HostConfig {
     int wmMinExact = 2, wmMaxExact = 8, wmMinLD1 = 3, wmMaxLD1 = 8;
     int maxDepth = 500;            // prefix DocSets with population > 20*maxDepth are never acceptable (only counted)
     int threads = 0;
+    SynMap syn;                    // SearchEngine(..., synonymMap): empty by default
 };
 
 struct HostIndex {
@@ -301,6 +302,7 @@ inline void build_index(const DocSource& src, HostIndex& ix) {
             }
             // Stage-2 / index text: lower(normalize(concat))   (VectorModel.cs:83-88)
             normalize_into(concat, it); lower_inplace(it);
+            if (cfg.syn.has()) cfg.syn.canonicalize(it);     // VectorModel.cs:90-93 (index text) and SearchPipeline.cs:482-489 (coverage text)
             textLen[d] = (uint32_t)it.size();
             textChunks[t].insert(textChunks[t].end(), it.begin(), it.end());
             // WordMatcher / word-IDF text: normalize(lower(concat))  (WordMatcher.cs:85-89, VectorModel.cs:885-889)

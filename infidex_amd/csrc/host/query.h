@@ -229,6 +229,7 @@ inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
     while (b < e && is_ws(raw[b])) b++;
     while (e > b && is_ws(raw[e - 1])) e--;
     normalize_into(raw.substr(b, e - b), P.qtext); lower_inplace(P.qtext);
+    if (ix.cfg.syn.has()) ix.cfg.syn.canonicalize(P.qtext);        // SearchEngine.cs:276-286
     bool allws = true; for (u16 c : P.qtext) if (!is_ws(c)) { allws = false; break; }
     if (allws) { P.blank = true; return; }
     normalize_into(P.qtext, P.searchText);

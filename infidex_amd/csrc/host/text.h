@@ -81,4 +81,50 @@ inline uint64_t hash_u16(const u16* p, size_t n) {
     return h;
 }
 
+
+// ---- synonyms ---------------------------------------------------------------------------------------------------------------
+// SynonymMap (Synonyms/SynonymMap.cs): tokens of one equivalence class are replaced by the class's canonical form in the index
+// text (VectorModel.cs:90-93), the query text (SearchEngine.cs:276-286) and the coverage document text (SearchPipeline.cs:482-489).
+// Union rule (:211-246): the longer root wins, equal lengths: ordinal order.  GetCanonical (:124-137) trims and lower-cases every
+// token, mapped or not.  Pairs are added before indexing; lookups afterwards are read-only (roots resolved eagerly).
+struct SynMap {
+    std::vector<std::pair<ustr, ustr>> parent;      // small (a handful of pairs): linear search
+    bool has() const { return !parent.empty(); }
+    static ustr trim_lower(uview t) {
+        size_t b = 0, e = t.size();
+        while (b < e && is_ws(t[b])) b++;
+        while (e > b && is_ws(t[e - 1])) e--;
+        ustr r(t.substr(b, e - b)); lower_inplace(r); return r;
+    }
+    int idx(const ustr& t) const { for (size_t i = 0; i < parent.size(); i++) if (parent[i].first == t) return (int)i; return -1; }
+    ustr root(ustr t) const { for (;;) { int i = idx(t); if (i < 0 || parent[i].second == t) return t; t = parent[i].second; } }
+    void add(uview a, uview b) {
+        auto blank = [](uview x) { for (u16 c : x) if (!is_ws(c)) return false; return true; };
+        if (blank(a) || blank(b)) return;
+        ustr t1 = trim_lower(a), t2 = trim_lower(b);
+        if (t1 == t2) return;
+        if (idx(t1) < 0) parent.push_back({t1, t1});
+        if (idx(t2) < 0) parent.push_back({t2, t2});
+        ustr r1 = root(t1), r2 = root(t2);
+        if (r1 == r2) return;
+        const bool firstWins = r1.size() != r2.size() ? r1.size() >= r2.size() : r1.compare(r2) <= 0;
+        const ustr& canon = firstWins ? r1 : r2; const ustr& other = firstWins ? r2 : r1;
+        parent[idx(other)].second = canon;
+    }
+    void canonicalize(ustr& text) const {            // CanonicalizeText with the tokenizer's delimiters
+        if (text.empty() || parent.empty()) return;
+        ustr out; out.reserve(text.size());
+        size_t i = 0;
+        while (i < text.size()) {
+            if (is_delim(text[i])) { out.push_back(text[i]); i++; continue; }
+            size_t st = i;
+            while (i < text.size() && !is_delim(text[i])) i++;
+            uview tok(text.data() + st, i - st);
+            bool blank = true; for (u16 c : tok) if (!is_ws(c)) { blank = false; break; }
+            if (blank) continue;
+            out += root(trim_lower(tok));
+        }
+        text.swap(out);
+    }
+};
 } // namespace infx

@@ -222,6 +222,11 @@ class SearchEngine:
         n = self.L.infx_engine_term_text(self.h, int(t), _p(buf, C.c_uint16), 256)
         return buf[:max(n, 0)].tobytes().decode("utf-16-le", errors="surrogatepass")
 
+    def add_synonym(self, a, b):
+        """SynonymMap.AddSynonym — before index_documents."""
+        ua, ub = _u16(a), _u16(b)
+        self._check(self.L.infx_engine_add_synonym(self.h, _p(ua, C.c_uint16), len(ua), _p(ub, C.c_uint16), len(ub)))
+
     def match_ld1_forward(self, q, cap=1024):
         a = _u16(q); out = np.zeros(cap, np.int32)
         c = self.L.infx_engine_match_ld1_forward(self.h, _p(a, C.c_uint16), len(a), _p(out, C.c_int32), cap)

@@ -16,6 +16,7 @@
 #pragma once
 #include "text.hpp"
 #include "dotnet.hpp"
+#include "synonyms.hpp"
 #include <unordered_map>
 #include <algorithm>
 #include <cstring>
@@ -56,6 +57,7 @@ inline float compute_idf(int totalDocs, int df) {   // Bm25Scorer.cs:686-695
 
 struct Index {
     Config cfg;
+    SynonymMap syn;                      // SearchEngine(..., synonymMap): empty unless a test adds pairs before indexing
     int N = 0;
     // documents
     std::vector<int64_t> docKey;
@@ -158,6 +160,7 @@ struct Index {
         textOff.push_back(textArena.size());
 
         ustr indexText = to_lower_inv(default_normalizer().normalize(concat));
+        if (syn.has()) indexText = syn.canonicalize(indexText);          // VectorModel.cs:90-93
         if (indexText.empty()) return;   // Tokenizer.cs:91-92
         // Tokenizer normalises again (idempotent on already-normalised text? not in general: lower-casing can
         // create new mappable chars) — restate literally:

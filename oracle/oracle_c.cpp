@@ -39,6 +39,10 @@ void* orc_create(int enable_coverage, int word_matcher, int stop_term_limit) {
     return new Handle(c);
 }
 void orc_destroy(void* h) { delete (Handle*)h; }
+// SynonymMap.AddSynonym (before any document is added)
+void orc_add_synonym(void* h, const uint16_t* a, int32_t la, const uint16_t* b, int32_t lb) {
+    ((Handle*)h)->eng.ix.syn.add(uview((const u16*)a, la), uview((const u16*)b, lb));
+}
 
 void orc_add_document(void* h, int64_t key, int nfields, const uint16_t* const* texts, const int32_t* lens, const int32_t* weights) {
     std::vector<FieldIn> f;

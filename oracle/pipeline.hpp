@@ -81,6 +81,7 @@ struct Engine {
         while (b < e && is_whitespace(rawQuery[b])) b++;
         while (e > b && is_whitespace(rawQuery[e - 1])) e--;
         ustr q = to_lower_inv(default_normalizer().normalize(rawQuery.substr(b, e - b)));
+        if (ix.syn.has()) q = ix.syn.canonicalize(q);                      // SearchEngine.cs:276-286
         return search_with(*s1, q, qp);
     }
     // q = trimmed, normalised, lower-cased query text; st = per-thread Stage-1 scratch (fuzzy LRU, upperBounds)
@@ -152,6 +153,7 @@ struct Engine {
             if (kit == keyToIndex.end()) return;
             int docIndex = kit->second;
             ustr docText = default_normalizer().normalize(ix.raw_text(internalId));
+            if (ix.syn.has()) docText = ix.syn.canonicalize(docText);       // SearchPipeline.cs:482-489
             int lcs = 0;
             if (docIndex < 2 && nDocs > 0) {
                 lcs = lcsRow[docIndex];

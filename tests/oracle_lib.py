@@ -87,6 +87,11 @@ class OracleEngine:
         except Exception:
             pass
 
+    def add_synonym(self, a, b):
+        """SynonymMap.AddSynonym — before indexing."""
+        ua, ub = u16(a), u16(b)
+        self.L.orc_add_synonym(self.h, _p(ua, C.c_uint16), len(ua), _p(ub, C.c_uint16), len(ub))
+
     def add(self, key, text_or_fields):
         """text_or_fields: str (single 'content' field, Weight.Med) or list of (text, weight)."""
         fields = [(text_or_fields, MED)] if isinstance(text_or_fields, str) else list(text_or_fields)

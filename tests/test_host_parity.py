@@ -156,3 +156,33 @@ def test_ld1_reverse_trie_equals_forward_walk():
         assert c1 == c2 and m1.tolist() == m2.tolist(), (w, c1, c2, m1[:8].tolist(), m2[:8].tolist())
         n_nonempty += c1 > 0
     assert n_nonempty > len(probes) // 4
+
+
+def test_school_corpus_with_synonyms_index_and_plans_match_oracle():
+    """Real Czech text (the reference's schools.json) + the three synonym pairs of SchoolSearchParityTests.cs: the product's host index
+    (canonicalised index text) and its query plans equal the oracle's."""
+    from tests import school_kats as SK
+    names = SK.load_names()
+    prod = SearchEngine.create_default(device=-1, threads=4)
+    orc = O.OracleEngine.create_default()
+    for a, b in SK.SYNONYMS:
+        prod.add_synonym(a, b); orc.add_synonym(a, b)
+    from infidex_amd import Document
+    prod.index_documents([Document(i, n) for i, n in enumerate(names)])
+    orc.index([(i, n) for i, n in enumerate(names)])
+    a, b = prod.export_index(), orc.export_index()
+    assert prod.index_stats()["terms"] == orc.num_terms
+    for k in ("df", "post_off", "post_doc", "post_w", "doc_len"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["avgdl"] == orc.avgdl
+    for q in ["mateřská škola lázně bělohrad", "gympl praha", "zs brno", "ss technická", "sciozlínskáškola", "scioškola če", "tyršovka česká lípa",
+              "ZŠ a MŠ", "Gympl  Brno", "belohradska"]:
+        p = prod.plan(q)
+        r = orc.search(q, 10)
+        if r["unsupported"]:
+            assert p["flags"] & 2
+            continue
+        t, df, idf, mx = orc.last_terms()
+        assert np.array_equal(p["term_ids"], t), q
+        assert np.array_equal(p["idf"], idf), q
+        assert np.array_equal(prod.wordmatcher(q), orc.wordmatcher(q)), q
