@@ -116,10 +116,46 @@ inline int match_ld1_forward(const HostIndex& ix, uview q, std::vector<int>& out
 // reversed trie anchors the match at the term END: an ordinary LD<=1 automaton over reverse(q) visits O(m * fan-out) nodes
 // (instead of every 1-2 character prefix of the vocabulary), and each accepted node is extended by the <= 2 junk characters.
 // Results are returned in the forward trie's pre-order (= lexicographic order of the terms), first `cap` kept, like the forward walk.
+// Words longer than 64 characters take the reference's Wagner-Fischer walk (FstIndex.MatchEditDistance1Slow, FstIndex.cs:362-440), which is a
+// DIFFERENT predicate: whole-term Levenshtein distance <= 1 (row[0] grows with the depth: no free start), subtrees pruned once
+// min(row) > 1, children visited in DESCENDING label order (ascending pushes on a LIFO stack), and the walk stops as soon as the
+// output buffer is full (so the count it returns is capped).
+inline int match_ld1_slow(const HostIndex& ix, uview q, std::vector<int>& out, int cap) {
+    out.clear();
+    const int m = (int)q.size();
+    if (ix.trie.empty() || cap <= 0) return 0;
+    struct Fr { uint32_t node; std::vector<int> row; };
+    std::vector<Fr> st;
+    { Fr f; f.node = 0; f.row.resize(m + 1); for (int i = 0; i <= m; i++) f.row[i] = i; st.push_back(std::move(f)); }
+    int count = 0;
+    while (!st.empty()) {
+        Fr f = std::move(st.back()); st.pop_back();
+        const auto& nd = ix.trie[f.node];
+        if (f.row[m] <= 1 && nd.term >= 0) { out.push_back(nd.term); if (++count >= cap) return count; }
+        int mn = f.row[0]; for (int i = 1; i <= m; i++) mn = std::min(mn, f.row[i]);
+        if (mn > 1) continue;
+        for (uint32_t e = ix.edgeStart[f.node]; e < ix.edgeStart[f.node + 1]; e++) {      // ascending pushes: popped in descending label order
+            const u16 c = ix.edgeLabel[e];
+            Fr g; g.node = ix.edgeChild[e]; g.row.resize(m + 1);
+            g.row[0] = f.row[0] + 1;
+            for (int i = 1; i <= m; i++) {
+                int v = g.row[i - 1] + 1;
+                if (f.row[i] + 1 < v) v = f.row[i] + 1;
+                const int sub = f.row[i - 1] + (q[i - 1] == c ? 0 : 1);
+                if (sub < v) v = sub;
+                g.row[i] = v;
+            }
+            st.push_back(std::move(g));
+        }
+    }
+    return count;
+}
+
 inline int match_ld1(const HostIndex& ix, uview q, std::vector<int>& out, int cap = 1024) {
     out.clear();
     const int m = (int)q.size();
-    if (m == 0 || m > 64 || ix.rEdgeStart.empty()) return 0;
+    if (m > 64) return match_ld1_slow(ix, q, out, cap);
+    if (m == 0 || ix.rEdgeStart.empty()) return 0;
     struct St { uint32_t node; int16_t i, d; uint8_t e; };
     St st[1024]; int sp = 0; std::vector<St> big;
     auto push = [&](uint32_t node, int i, int e, int d) { St x{node, (int16_t)i, (int16_t)d, (uint8_t)e}; if (sp < 1024) st[sp++] = x; else big.push_back(x); };

@@ -186,3 +186,28 @@ def test_school_corpus_with_synonyms_index_and_plans_match_oracle():
         assert np.array_equal(p["term_ids"], t), q
         assert np.array_equal(p["idf"], idf), q
         assert np.array_equal(prod.wordmatcher(q), orc.wordmatcher(q)), q
+
+
+def test_ld1_fst_kats_and_long_words():
+    """FstIndexTests.cs restated on an index: 'applz' matches {apple, apply}; 'apple' matches {apple, apples, apply, bpple}; the count is
+    the total even when the buffer is smaller (:58-73); words longer than 64 characters take the slow whole-term path (:101-126):
+    the 70-letter term and its distance-1 variant match, the distance-2 variant does not.  Product == oracle on all of them."""
+    from infidex_amd import Document
+    long_a = "a" * 70; long_b = "a" * 69 + "b"; long_c = "a" * 68 + "bb"
+    docs = [(0, "apple apples apply bpple"), (1, long_a + " " + long_b + " " + long_c), (2, "unrelated words here")]
+    prod = SearchEngine.create_default(device=-1); prod.index_documents([Document(k, t) for k, t in docs])
+    orc = O.OracleEngine.create_default(); orc.index(docs)
+
+    def texts(eng, q, cap=1024):
+        c, m = eng.match_ld1(q, cap)
+        return c, [eng.term_text(int(t)) for t in m]
+    for eng in (prod, orc):
+        c, t = texts(eng, "applz"); assert c == 2 and set(t) == {"apple", "apply"}, (c, t)
+        c, t = texts(eng, "apple"); assert c == 4 and set(t) == {"apple", "apples", "apply", "bpple"}, (c, t)
+        c, t = texts(eng, "apple", 1); assert c == 4 and len(t) == 1
+        c, t = texts(eng, long_a); assert set(t) == {long_a, long_b}, (c, [len(x) for x in t])
+    for q in ("applz", "apple", "bpple", long_a, long_b, long_c, "a" * 65, "a" * 71):
+        c1, m1 = prod.match_ld1(q); c2, m2 = orc.match_ld1(q)
+        assert c1 == c2 and m1.tolist() == m2.tolist(), (q[:8], len(q), c1, c2)
+    c1, m1 = prod.match_ld1(long_a, 1); c2, m2 = orc.match_ld1(long_a, 1)
+    assert c1 == c2 == 1 and m1.tolist() == m2.tolist()            # the slow path stops when the buffer is full
