@@ -143,3 +143,30 @@ np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f)
     for i in range(len(a["c"])):
         n = int(a["c"][i])
         assert np.array_equal(a["k"][i, :n], b["k"][i, :n]) and np.array_equal(a["sc"][i, :n], b["sc"][i, :n]) and np.array_equal(a["t"][i, :n], b["t"][i, :n])
+
+
+def test_concurrent_sessions_match_sequential_results(corpus):
+    """ThreadSafetyTests.cs:16-43,139-175 (many readers under the read lock): several host threads, one engine session each, searching the
+    same index at once return exactly what a sequential caller gets."""
+    import threading
+    from infidex_amd import Session
+    _, _, _, e, texts = corpus
+    batches = [texts[i:i + 100] for i in range(0, 800, 100)]
+    expect = [run(e, b) for b in batches]
+    sessions = [Session(e) for _ in range(4)]
+    got = [None] * len(batches); errors = []
+
+    def worker(w):
+        try:
+            for rep in range(3):
+                for bi in range(w, len(batches), 4):
+                    a, o = pack_texts(batches[bi])
+                    got[bi] = sessions[w].search_packed(a, o, K)
+        except Exception as ex:   # surfaced below
+            errors.append(ex)
+    ths = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert not errors, errors
+    for g, x in zip(got, expect):
+        for u, v in zip(g, x):
+            assert np.array_equal(u, v)
