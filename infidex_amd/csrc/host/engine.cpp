@@ -30,6 +30,7 @@ inline int cmp_entry(const Entry& a, const Entry& b) {    // ScoreEntry.CompareT
 
 // One in-flight batch: its own HIP stream + scratch. Several sessions on one engine let the host preparation of one batch
 // overlap the GPU stages of another (SearchEngine.Search is callable from many threads concurrently, SearchEngine.cs:258).
+struct FusedIn;
 struct PerQ {
     std::vector<Entry> stage1;          // consolidated Stage-1 (score desc, key asc)
     std::vector<int32_t> stage1Doc;     // global internal ids
@@ -45,6 +46,7 @@ struct Batch {
     std::vector<uint32_t> localIdx;     // local Stage-2 candidates -> position in lastCands
     std::vector<std::shared_ptr<FuzzyUnion>> pending; std::vector<uint32_t> pendingCounts; std::unordered_map<const FuzzyUnion*, uint32_t> unionIdx;   // unions whose df this batch counts
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tPlanPar = 0, tTok = 0, tUnion = 0;
+    std::shared_ptr<FusedIn> pre;      // sharded phases: per-query device-pipeline inputs prepared in phase 0 (off the collective path)
 };
 
 struct infx_session {
@@ -535,7 +537,7 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
             const QueryPlan& P = plans[i]; infx_fused_query& F = fq[i];
             F = infx_fused_query{}; F.dev = -1; F.max_results = max_results;
             if (P.blank || P.unsupported) { F.flags = INFX_FQ_SKIP | (P.unsupported ? INFX_FQ_UNSUPPORTED : 0u); continue; }
-            F.dev = B.devOf[i];
+            F.dev = B.devOf.empty() ? -1 : B.devOf[i];      // (pre-built in phase 0: filled in by fused_inputs_for_phase3)
             const ustr& st = P.searchText;
             bool isShort = !st.empty() && st.size() <= 3;
             if (isShort) for (u16 ch : st) if (is_delim(ch)) { isShort = false; break; }
@@ -563,6 +565,23 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
         owned.insert(owned.end(), qOwned[i].begin(), qOwned[i].end());
     }
     if (owned.size() > 0xFFFFFFF0ull) return efail(INFX_ECAPACITY, "affix matches of this batch exceed 2^32 ids; split the batch");
+    return INFX_OK;
+}
+
+// Sharded phases: phase 0 (which may run on a planner thread while another batch is in its collective phases) prepares the inputs;
+// phase 3 only fills in what it learns later (the Stage-1 query index, max_results, the caller's coverage switch).
+static int32_t fused_inputs_for_phase3(infx_engine* e, infx_session* S, int32_t max_results, int32_t enable_coverage, std::shared_ptr<FusedIn>& out) {
+    Batch& B = *S->batch;
+    if (!B.pre) { B.pre = std::make_shared<FusedIn>(); int32_t rc = build_fused_inputs(e, S, max_results, 1, *B.pre); if (rc) return rc; }
+    FusedIn& F = *B.pre;
+    const bool cov = e->ix.cfg.enableCoverage && enable_coverage;
+    for (uint32_t i = 0; i < B.nq; i++) {
+        infx_fused_query& q = F.fq[i];
+        q.max_results = max_results;
+        if (!(q.flags & INFX_FQ_SKIP)) q.dev = B.devOf.empty() ? -1 : B.devOf[i];
+        if (!cov) { q.flags &= ~INFX_FQ_COV; q.wm_count = 0; }
+    }
+    out = B.pre;
     return INFX_OK;
 }
 
@@ -677,6 +696,11 @@ int32_t infx_session_phase0(infx_session* S, uint32_t nq, const uint16_t* q_aren
     if (!S) return efail(INFX_EINVAL, "null session");
     int32_t rc = ph_plan(S->e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
     if (nunions) *nunions = (uint32_t)S->batch->pending.size();
+    static const bool hostPhases = getenv("INFX_PHASED") != nullptr;
+    if (!hostPhases && nq) {     // WordMatcher descriptors + PrepareQuery now: phase 0 is off the collective path (sharded.py search_stream)
+        S->batch->pre = std::make_shared<FusedIn>();
+        rc = build_fused_inputs(S->e, S, 1, 1, *S->batch->pre); if (rc) return rc;
+    }
     return INFX_OK;
 }
 int32_t infx_session_union_counts(infx_session* S, uint32_t* counts) {   // this shard's |union| of every pending fuzzy virtual term
@@ -731,7 +755,8 @@ int32_t infx_session_phase3(infx_session* S, int32_t W, const infx_hit* all_hits
     }
     infx_engine* e = S->e; Batch& B = *S->batch;
     B.maxResults = max_results;
-    FusedIn FI; int32_t rc = build_fused_inputs(e, S, max_results, enable_coverage, FI); if (rc) return rc;
+    std::shared_ptr<FusedIn> FIp; int32_t rc = fused_inputs_for_phase3(e, S, max_results, enable_coverage, FIp); if (rc) return rc;
+    FusedIn& FI = *FIp;
     B.t3 = now_ms();
     S->lastOuts.assign((size_t)B.nq * 2 * B.depth, infx_cov_out{});
     if (B.nq) {
@@ -766,7 +791,8 @@ int32_t infx_session_phase3x(infx_session* S, int32_t W, const void* all_hits, c
     if (!S || W < 1 || max_results < 1 || !outs) return efail(INFX_EINVAL, "bad arguments");
     infx_engine* e = S->e; Batch& B = *S->batch;
     B.maxResults = max_results;
-    FusedIn FI; int32_t rc = build_fused_inputs(e, S, max_results, enable_coverage, FI); if (rc) return rc;
+    std::shared_ptr<FusedIn> FIp; int32_t rc = fused_inputs_for_phase3(e, S, max_results, enable_coverage, FIp); if (rc) return rc;
+    FusedIn& FI = *FIp;
     B.t3 = now_ms();
     if (B.nq) {
         rc = infx_shard_stage2(S->stream, W, B.nd, (const infx_hit*)all_hits, (const uint32_t*)all_counts, B.nq, FI.fq.data(), FI.cq.data(), (uint32_t)FI.lists.size(), FI.lists.data(),
