@@ -553,6 +553,16 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
                 else { L.src = 2; L.off = qOwned[i].size(); qOwned[i].insert(qOwned[i].end(), l.p, l.p + l.n); }
                 qLists[i].push_back(L);
             }
+            if (qLists[i].size() > INFX_MAX_WM_LISTS) {
+                // very long queries: the device probes at most INFX_MAX_WM_LISTS lists per query, so the lists are merged here into ONE
+                // ascending list (membership in any list / first-unique over the union are unchanged by the merge)
+                std::vector<int32_t> all;
+                for (auto& l : wm.lists) all.insert(all.end(), l.p, l.p + l.n);
+                std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
+                qOwned[i].swap(all);
+                infx_wm_list L{}; L.src = 2; L.off = 0; L.len = (uint32_t)qOwned[i].size();
+                qLists[i].assign(1, L);
+            }
             covErr[i] = prepare_cov_query(ix, st, cq[i]);
         }
     });

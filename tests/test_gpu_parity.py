@@ -241,3 +241,16 @@ def test_batches_without_any_index_term():
     res = e.search_batch(qs, 10)
     for q, r in zip(qs, res):
         assert [x.document_id for x in r.records] == o.search(q, 10)["keys"], q
+
+
+def test_query_with_more_wordmatcher_lists_than_the_device_limit():
+    """A 30-word query produces more WordMatcher lists than INFX_MAX_WM_LISTS (256): the host merges them into one list; results match the oracle."""
+    import random
+    rng = random.Random(11)
+    words = ["".join(rng.choice("abcdefghij") for _ in range(rng.choice([4, 5, 6, 7]))) for _ in range(400)]
+    docs = [(i, " ".join(rng.choice(words) for _ in range(rng.choice([6, 10, 14])))) for i in range(3000)]
+    e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+    o = O.OracleEngine.create_default(); o.index(docs)
+    q = " ".join(words[i] for i in range(0, 300, 10))          # 30 distinct index words
+    st = compare_batch(e, o, [q, "abcd efgh", q[: len(q) // 2]], 10)
+    assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, st
