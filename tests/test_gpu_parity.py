@@ -254,3 +254,14 @@ def test_query_with_more_wordmatcher_lists_than_the_device_limit():
     q = " ".join(words[i] for i in range(0, 300, 10))          # 30 distinct index words
     st = compare_batch(e, o, [q, "abcd efgh", q[: len(q) // 2]], 10)
     assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, st
+
+
+def test_random_unicode_corpora_full_parity():
+    """End to end on random text with diacritics, mixed case, all delimiters, odd whitespace, empty / one-character / duplicate documents."""
+    from tests import unicode_corpus
+    for seed in range(3):
+        docs, queries = unicode_corpus.make(seed, ndocs=600, nqueries=80)
+        e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+        o = O.OracleEngine.create_default(); o.index(docs)
+        st = compare_batch(e, o, queries, 10)
+        assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, (seed, st)

@@ -211,3 +211,31 @@ def test_ld1_fst_kats_and_long_words():
         assert c1 == c2 and m1.tolist() == m2.tolist(), (q[:8], len(q), c1, c2)
     c1, m1 = prod.match_ld1(long_a, 1); c2, m2 = orc.match_ld1(long_a, 1)
     assert c1 == c2 == 1 and m1.tolist() == m2.tolist()            # the slow path stops when the buffer is full
+
+
+def test_random_unicode_corpora_index_and_plans_match_oracle():
+    """Two independent implementations (product host C++ vs oracle) on random text with diacritics, mixed case, every delimiter of
+    ConfigurationParameters.cs:58-62, digits, odd whitespace, repeated words, empty and one-character documents, duplicate texts."""
+    from infidex_amd import Document
+    from tests import unicode_corpus
+    for seed in range(6):
+        docs, queries = unicode_corpus.make(seed)
+        prod = SearchEngine.create_default(device=-1, threads=3); prod.index_documents([Document(k, t) for k, t in docs])
+        orc = O.OracleEngine.create_default(); orc.index(docs)
+        a, b = prod.export_index(), orc.export_index()
+        assert prod.index_stats()["terms"] == orc.num_terms, seed
+        for k in ("df", "post_off", "post_doc", "post_w", "doc_len"):
+            assert np.array_equal(a[k], b[k]), (seed, k)
+        assert a["avgdl"] == orc.avgdl
+        for q in queries:
+            p = prod.plan(q)
+            r = orc.search(q, 10)
+            if r["unsupported"]:
+                assert p["flags"] & 2, (seed, q)
+                continue
+            t, df, idf, mx = orc.last_terms()
+            assert np.array_equal(p["term_ids"], t), (seed, q)
+            assert np.array_equal(p["idf"], idf), (seed, q)
+            # the pipeline hands WordMatcherLookup the NORMALISED search text (SearchPipeline.cs:98-104); the product hook normalises itself
+            from infidex_amd.engine import normalize as _norm
+            assert np.array_equal(prod.wordmatcher(q), orc.wordmatcher(_norm(q, lower=True))), (seed, q)
