@@ -239,3 +239,30 @@ def test_random_unicode_corpora_index_and_plans_match_oracle():
             # the pipeline hands WordMatcherLookup the NORMALISED search text (SearchPipeline.cs:98-104); the product hook normalises itself
             from infidex_amd.engine import normalize as _norm
             assert np.array_equal(prod.wordmatcher(q), orc.wordmatcher(_norm(q, lower=True))), (seed, q)
+
+
+def test_random_synonym_maps_index_identically():
+    """SynonymMap union-find (longer root wins, ordinal tie-break, chains, repeated and self pairs, mixed case): product == oracle."""
+    import random
+    from infidex_amd import Document
+    from tests import unicode_corpus
+    for seed in range(4):
+        docs, queries = unicode_corpus.make(20 + seed, ndocs=200, nqueries=20)
+        rng = random.Random(seed)
+        words = sorted({w for _, t in docs for w in t.replace("\t", " ").replace("\n", " ").split(" ") if 2 <= len(w) <= 8})[:60]
+        pairs = [(rng.choice(words), rng.choice(words)) for _ in range(12)] + [(words[0], words[1]), (words[1], words[2]), (words[2].upper(), words[3]), (words[4], words[4])]
+        prod = SearchEngine.create_default(device=-1, threads=2); orc = O.OracleEngine.create_default()
+        for a, b in pairs:
+            prod.add_synonym(a, b); orc.add_synonym(a, b)
+        prod.index_documents([Document(k, t) for k, t in docs]); orc.index(docs)
+        x, y = prod.export_index(), orc.export_index()
+        assert prod.index_stats()["terms"] == orc.num_terms, seed
+        for k in ("df", "post_off", "post_doc", "post_w", "doc_len"):
+            assert np.array_equal(x[k], y[k]), (seed, k)
+        for q in queries:
+            p = prod.plan(q); r = orc.search(q, 10)
+            if r["unsupported"]:
+                assert p["flags"] & 2
+                continue
+            t, df, idf, mx = orc.last_terms()
+            assert np.array_equal(p["term_ids"], t), (seed, q)
