@@ -30,6 +30,7 @@ typedef struct infx_engine_config {
     int32_t word_matcher;     /* CreateDefault: 1 (config 400 WordMatcherSetup), CreateMinimal: 0 */
     int32_t stop_term_limit;  /* 0 = 1 250 000 */
     int32_t want_features;    /* 1: Stage 2 also returns the integer feature vector (parity tests) */
+    int32_t no_exact_replay;  /* 1: INFX_CFG_NO_EXACT_REPLAY (infidex_hip.h) — Stage-1 cut ties by (score, doc id) instead of the reference's heap order */
 } infx_engine_config;
 
 const char* infx_engine_last_error(void);
@@ -56,7 +57,7 @@ void    infx_engine_session_destroy(infx_session* s);
 int32_t infx_engine_session_search_batch(infx_session* s, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
                                          int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                          uint32_t* out_counts, uint32_t* out_flags);
-int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, float* kernel_ms5, uint64_t* alg5);
+int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, float* kernel_ms5, uint64_t* alg6);
 
 /* Document-sharded operation: every rank indexes the whole corpus on the host (global df / avgdl / N), uploads
  * its contiguous doc range, and a batch runs as four phases with the collectives in between:
@@ -92,9 +93,9 @@ int32_t infx_session_phase4(infx_session* s, const int32_t* merged_outs3, int64_
  * pipeline, one synchronisation); final ordering on the host (phase API only);
  * kernel_ms5: accumulate, rules + select, stage2, and for the fused pipeline candidate assembly (k_prep2) and final ordering
  * (k_finalize) — kernel durations from HIP events on the launch stream;
- * alg (5 entries): algorithmic bytes of the accumulate launch per SURVEY 8(d), Stage-2 candidate count, Stage-2 text bytes,
- * bytes the accumulate launch actually streamed, Stage-1 candidates. */
-int32_t infx_engine_last_timings(infx_engine* e, double* host_ms5, float* kernel_ms5, uint64_t* alg5);
+ * alg (6 entries): algorithmic bytes of the accumulate launch per SURVEY 8(d), Stage-2 candidate count, Stage-2 text bytes,
+ * bytes the accumulate launch actually streamed, Stage-1 candidates, queries replayed by k_exact1. */
+int32_t infx_engine_last_timings(infx_engine* e, double* host_ms5, float* kernel_ms5, uint64_t* alg6);
 
 /* ---- introspection used by the parity tests (host logic runs without a GPU) ---- */
 int32_t infx_engine_index_stats(infx_engine* e, int64_t* n_docs, int64_t* n_terms, int64_t* n_postings, float* avgdl);
@@ -112,6 +113,8 @@ int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* doc
 /* CPUs usable by this process: hardware threads capped by the affinity mask and the cgroup CPU quota (INFX_THREADS overrides);
  * the default size of the host worker pool and of `threads`. */
 int32_t infx_engine_effective_cpus(void);
+/* Switches infx_engine_config.want_features at run time (the introspection buffers behind infx_engine_last_stage1 / _last_stage2). */
+int32_t infx_engine_set_introspection(infx_engine* e, int32_t on);
 int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uint16_t* out, int32_t cap);
 int32_t infx_engine_device_handles(infx_engine* e, infx_index** idx, infx_stream** st);
 

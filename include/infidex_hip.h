@@ -46,8 +46,13 @@ typedef struct infx_config {
     int32_t range_docs;      /* documents per LDS range block (power of two, 512..16384); 0 = chosen from the shard size at
                                 infx_upload_docs: 1024 below 256k documents ... 8192 from 4M documents */
     int32_t max_depth;       /* largest Query.CoverageDepth that will be used (default 500) */
-    int32_t reserved;
+    int32_t flags;           /* INFX_CFG_* */
 } infx_config;
+/* Queries whose Stage-1 top-`depth` cut is ambiguous (rows within a few ulp of each other around the cut, exact ties included) are
+ * replayed with the reference's sequential semantics — chunked Vector256 / scalar-tail BM25 rounding (Bm25Scorer.cs:395-444) and the
+ * BCL PriorityQueue eviction order (Bm25Scorer.cs:654-670) — by k_exact1, so the Stage-1 set and scores are the reference's bit for
+ * bit.  This flag turns the replay off (the cut is then taken by (score, doc id)); document shards always run without it. */
+#define INFX_CFG_NO_EXACT_REPLAY 1
 
 int32_t infx_create(const infx_config* cfg, infx_index** out);
 void    infx_destroy(infx_index* idx);
@@ -247,6 +252,8 @@ int32_t infx_last_timings(infx_stream* s, float* accumulate_ms, float* select_ms
 int32_t infx_last_alg_bytes(infx_stream* s, uint64_t* bytes);
 /* Sum over the batch of card(C_q): candidates the tier rules let through (upper bound +128/query in disjunctive mode). */
 int32_t infx_last_candidates(infx_stream* s, uint64_t* n);
+/* Queries of the last batch whose Stage-1 cut was ambiguous and was replayed with the reference's sequential semantics (k_exact1). */
+int32_t infx_last_exact_replays(infx_stream* s, uint32_t* n);
 
 #ifdef __cplusplus
 }

@@ -54,7 +54,7 @@ struct infx_session {
     Batch* batch = nullptr;
     infx_stream* stream = nullptr;
     double tPrep1 = 0, tStage1 = 0, tPrep2 = 0, tStage2 = 0, tPost = 0;
-    float msAcc = 0, msSel = 0, msCov = 0, msPrep2 = 0, msFin = 0; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0;
+    float msAcc = 0, msSel = 0, msCov = 0, msPrep2 = 0, msFin = 0; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0; uint32_t exactReplays = 0;
     // last-batch introspection for parity tests
     std::vector<QueryPlan> lastPlans;
     std::vector<infx_hit> lastHits; std::vector<uint32_t> lastHitCount; int lastStride = 0;
@@ -92,7 +92,7 @@ int32_t infx_engine_create(const infx_engine_config* cfg, infx_engine** out) {
     h.threads = cfg->threads;
     e->threads = cfg->threads > 0 ? cfg->threads : effective_cpus();
     if (cfg->device >= 0) {
-        infx_config dc{}; dc.device = cfg->device; dc.range_docs = cfg->range_docs; dc.max_depth = h.maxDepth;
+        infx_config dc{}; dc.device = cfg->device; dc.range_docs = cfg->range_docs; dc.max_depth = h.maxDepth; dc.flags = cfg->no_exact_replay ? INFX_CFG_NO_EXACT_REPLAY : 0;
         int32_t rc = infx_create(&dc, &e->dev);
         if (rc) { g_eerr = infx_last_error(); delete e; return rc; }
     }
@@ -288,7 +288,7 @@ static int32_t ph_select(infx_engine* e, infx_session* S, const infx_counts* glo
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
         infx_last_alg_bytes(S->stream, &S->streamedBytes);
-        infx_last_candidates(S->stream, &S->s1Candidates);
+        infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays);
         // B_alg(q) = sum_t df_t * 5 B (4 B for fuzzy virtual terms) + card(C_q) * 4 B + depth * 12 B   (this shard's slices)
         uint64_t ab = 0;
         for (auto& t : B.dterms) {
@@ -616,7 +616,7 @@ static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, 
     float ms5[5] = {0, 0, 0, 0, 0}; infx_last_fused_timings(S->stream, ms5);
     S->msAcc = ms5[0]; S->msSel = ms5[1]; S->msPrep2 = ms5[2]; S->msCov = ms5[3]; S->msFin = ms5[4];
     uint64_t s1rows = 0; infx_last_fused_stats(S->stream, &s1rows, &S->s2Candidates, &S->s2TextBytes);
-    infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates);
+    infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays);
     {   // B_alg(q) = sum_t df_t * 5 B (4 B for fuzzy virtual terms) + card(C_q) * 4 B + depth * 12 B
         uint64_t ab = 0;
         for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
@@ -744,7 +744,7 @@ int32_t infx_session_phase2(infx_session* S, const uint32_t* global_counts, infx
         int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, S->lastHits.data(), S->lastHitCount.data());
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
-        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates);
+        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays);
         uint64_t ab = 0, nh = 0;
         for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)S->e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
         for (uint32_t c : S->lastHitCount) nh += c;
@@ -789,7 +789,7 @@ int32_t infx_session_phase2x(infx_session* S, const uint32_t* global_counts, voi
         int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, (infx_hit*)hits, (uint32_t*)hitcounts);
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
-        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates);
+        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays);
         uint64_t ab = 0;
         for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)S->e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
         S->algBytes = ab + S->s1Candidates * 4ull + (uint64_t)B.nd * B.depth * 12ull;
@@ -839,7 +839,7 @@ int32_t infx_engine_session_last_timings(infx_session* S, double* host_ms5, floa
     if (!S) return efail(INFX_EINVAL, "null");
     if (host_ms5) { host_ms5[0] = S->tPrep1; host_ms5[1] = S->tStage1; host_ms5[2] = S->tPrep2; host_ms5[3] = S->tStage2; host_ms5[4] = S->tPost; }
     if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; kernel_ms3[3] = S->msPrep2; kernel_ms3[4] = S->msFin; }
-    if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; }
+    if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; alg_bytes3[5] = S->exactReplays; }
     return INFX_OK;
 }
 
@@ -848,7 +848,7 @@ int32_t infx_engine_last_timings(infx_engine* e, double* host_ms5, float* kernel
     infx_session* S = e->def;
     if (host_ms5) { host_ms5[0] = S->tPrep1; host_ms5[1] = S->tStage1; host_ms5[2] = S->tPrep2; host_ms5[3] = S->tStage2; host_ms5[4] = S->tPost; }
     if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; kernel_ms3[3] = S->msPrep2; kernel_ms3[4] = S->msFin; }
-    if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; }
+    if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; alg_bytes3[5] = S->exactReplays; }
     return INFX_OK;
 }
 
@@ -942,6 +942,8 @@ int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* doc
     return n;
 }
 int32_t infx_engine_effective_cpus(void) { return effective_cpus(); }
+// parity tooling: switch the introspection downloads (Stage-1 rows, Stage-2 candidates / features of the last batch) on or off at run time
+int32_t infx_engine_set_introspection(infx_engine* e, int32_t on) { if (!e) return INFX_EINVAL; e->cfg.want_features = on ? 1 : 0; return INFX_OK; }
 
 int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uint16_t* out, int32_t cap) {
     ustr r = normalize(uview((const u16*)s, len)); if (lower) lower_inplace(r);

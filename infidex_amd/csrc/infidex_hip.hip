@@ -39,6 +39,8 @@ struct DevIndex {
     int32_t N, T, R, rshift, nRanges, docBase, totalDocs;
     const uint64_t* postOff; const int32_t* postDoc; const uint8_t* postW;
     const float* docNorm;      // K1*((1-B) + (B/avgdl)*dl) — the 8-lane formula of Bm25Scorer.cs:413-416
+    const float* docLen;       // VectorModel._docLengths (the scalar-tail formula of ComputeTermScore needs dl / avgdl, k_exact1)
+    const uint8_t* deleted;    // Document.Deleted per shard-local doc (nullptr = none)
     const int64_t* docKey;
     const uint64_t* textOff; const uint16_t* text;
     const uint32_t* skipIdx;   // per term: first entry in skipTbl, or 0xFFFFFFFF
@@ -62,6 +64,7 @@ struct infx_index {
     std::vector<uint64_t> hPostOff;   // host copy of the (padded) list starts
     std::vector<uint64_t> hPostLen;   // true list lengths
     std::vector<int32_t> hDf;
+    std::vector<uint32_t> hSkipIdx;   // host copy of DevIndex::skipIdx (filled by infx_upload_postings)
     std::vector<uint64_t> hPsOff;
     int rank = 0, nranks = 1;
 };
@@ -117,11 +120,13 @@ struct DevTerm {           // per (query term), device layout
     uint64_t begin, end;   // absolute posting slice in postDoc/postW, or in extraDocs for virtual terms
     float idf;
     uint32_t skip;         // skipTbl base or 0xFFFFFFFF
-    uint8_t role, rank, isVirtual, pad;
+    uint8_t role, rank, isVirtual, pad;   // pad = fuzzy-union dedupe group (member-list terms), 0 = none
+    uint16_t refIdx, pad2; // position of the term in the query's Bm25Scorer order (member lists share their virtual term's position)
 };
 struct DevQuery {
     uint32_t termOff, numTerms;
     int32_t mode, prefixSet, depth, nAnd;
+    uint32_t refOff, numRef;   // the query's terms as the caller passed them (Bm25Scorer order): DevRefTerm[refOff .. +numRef)
 };
 struct SelRule {           // decided on the host from the (global) class counts
     int32_t mode;          // INFX_MODE_*
@@ -151,6 +156,7 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 }
 
 #include "stage1.hip.inc"
+#include "exact1.hip.inc"
 #include "stage2.hip.inc"
 
 // TieredCandidateSelector tier rules evaluated from class counts (see header of this file / DESIGN.md)
@@ -230,6 +236,10 @@ struct infx_stream {
     void* dCovO = nullptr; size_t capCovO = 0;
     void* dCovF = nullptr; size_t capCovF = 0;
     int32_t* arDoc = nullptr; float* arScore = nullptr; uint8_t* arCls = nullptr; size_t arCap = 0;
+    unsigned long long* arMask = nullptr; size_t arMaskCap = 0; int maskWords = 0;     // per-row hit masks of the last accumulate launch
+    void* dDir = nullptr; size_t capDir = 0;
+    void* dRefTerms = nullptr; size_t capRefTerms = 0; void* dExactFlag = nullptr; size_t capExactFlag = 0; uint32_t* dExactStat = nullptr;   // k_exact1 inputs
+    uint32_t lastExact = 0;                                                              // queries replayed exactly in the last batch                                            // (query, range) chunk directory
     unsigned long long* dCursor = nullptr;   // [0]=cursor [1]=algBytes
     uint32_t* dOverflow = nullptr;
     std::vector<infx_query> lastQ;            // kept between accumulate and select
@@ -280,6 +290,9 @@ static int32_t stream_sync(infx_stream* s) {
     return INFX_OK;
 }
 static int32_t pin_reset(infx_stream* s) {     // start of an API call: the staging of the previous call must have been consumed
+    // Outputs still pending here belong to a call that returned before its own synchronisation (an error path): their destinations
+    // (often that call's stack variables) are gone, so they are dropped, never copied.
+    s->pendingOut.clear();
     if (s->unsynced) { int32_t rc = stream_sync(s); if (rc) return rc; }
     for (auto& c : s->pins) c.off = 0;
     return INFX_OK;
@@ -340,15 +353,45 @@ static void launch_union_any(infx_stream* s, uint32_t nv, const uint32_t* dOffs,
         default: launch_union<16384>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
     }
 }
+// exact replay of the reference's Stage-1 order effects (k_exact1) — on unless INFX_EXACT=0
+static bool exact_enabled(const infx_index* ix) { static const bool v = [] { const char* e = getenv("INFX_EXACT"); return !(e && e[0] == '0'); }(); return v && !(ix->cfg.flags & INFX_CFG_NO_EXACT_REPLAY); }
+static Arena make_arena(infx_stream* s) {
+    return Arena{s->arDoc, s->arScore, s->arCls, s->arMask, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
+                 (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes, (uint2*)s->dDir, s->maskWords};
+}
+static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX_ACC_STRIPE"); int x = e ? atoi(e) : 0; return (x >= 1 && x <= 64) ? x : 4; }(); return v; }
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp) {
-    static const int cap = [] { const char* e = getenv("INFX_ACC_CAP"); int v = e ? atoi(e) : 0; return (v >= 64 && v <= 4096 && (v & 63) == 0) ? v : ACC_CAP_DEFAULT; }();
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
-    size_t lds = (size_t)(R / 32) * 6 + 8 + (size_t)cap * (12 + (useGrp ? 1 : 0)) + (size_t)(maxT + 1) * sizeof(TermLds) + INFX_NCLASS * 4;   // sized by the batch's longest query
-    uint64_t blocks = (uint64_t)nq * s->ix->d.nRanges;
-    k_accumulate<R><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, cap, useGrp, dbgSkip, (unsigned long long*)s->dStats);
+    const int stripe = acc_stripe();
+    const size_t lds = (size_t)R + 128 + (size_t)(maxT + 1) * sizeof(TermLds) + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + (size_t)(R / 32) * 2 + ACC_CAP_DEFAULT * 2;   // sized by the batch's longest query
+    const uint64_t blocks = (uint64_t)nq * ((s->ix->d.nRanges + stripe - 1) / stripe);
+    if (ar.maskWords == 2)
+        k_accumulate<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats);
+    else
+        k_accumulate<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats);
     if (dbgSkip & 8) { unsigned long long h[4] = {0, 0, 0, 0}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 32, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 32);
         fprintf(stderr, "[infx] k_accumulate stats: %llu blocks with candidates of %llu, %.2f rounds/block, %.1f candidates/block\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0); }
+}
+
+// k_exact1 behind k_select: unsharded indexes only (the reference's chunking follows GLOBAL 65 536-id containers and its heap is sequential
+// over the whole corpus; document shards keep k_select's deterministic (score, doc id) cut)
+static bool exact_possible(infx_stream* s) { return exact_enabled(s->ix) && s->maskWords > 0 && s->ix->nranks == 1 && s->ix->d.docBase == 0; }
+static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
+    infx_index* ix = s->ix;
+    const int MW = s->maskWords, depthCap = ix->cfg.max_depth;
+    const size_t lds = (size_t)(EX_CHUNK + EX_THREADS) * MW * 8 + (size_t)(EX_CHUNK + EX_THREADS) * 4 + (size_t)EX_CHUNK * 4 + (size_t)depthCap * 8 +
+                       (INFX_MAX_QUERY_TERMS + 1) * 4 + 130 * 4 + 129 * 4 + 8 * 4 + (size_t)EX_CHUNK * 2 + 64;
+    static std::mutex mu; static size_t attrSet = 0;
+    { std::lock_guard<std::mutex> lk(mu); if (lds > attrSet) { HIPCHK(hipFuncSetAttribute((const void*)k_exact1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; } }
+    Arena ar = make_arena(s);
+    HIPCHK(hipMemsetAsync(s->dExactStat, 0, 4, s->st));
+    k_exact1<<<nq, EX_THREADS, lds, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag,
+                                             ix->avgdl, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, depthCap, s->dExactStat);
+    HIPCHK(hipGetLastError());
+    DOWN(&s->lastExact, s->dExactStat, 4);          // lands at the caller's stream synchronisation
+    return INFX_OK;
 }
 
 extern "C" {
@@ -385,15 +428,13 @@ int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float
     if (!ix || !doc_len || !doc_key) return fail(INFX_EINVAL, "null argument%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
     float *dLen = nullptr, *dNorm = nullptr; int64_t* dKey = nullptr; uint64_t* dTO = nullptr; uint16_t* dTx = nullptr;
-    HIPCHK(dalloc(ix, &dNorm, N)); HIPCHK(dalloc(ix, &dKey, N));
-    HIPCHK(hipMalloc((void**)&dLen, std::max<size_t>(N, 1) * 4));
+    HIPCHK(dalloc(ix, &dNorm, N)); HIPCHK(dalloc(ix, &dKey, N)); HIPCHK(dalloc(ix, &dLen, N));
     HIPCHK(hipMemcpy(dLen, doc_len, (size_t)N * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dKey, doc_key, (size_t)N * 8, hipMemcpyHostToDevice));
     float a = avgdl > 0.f ? avgdl : 1.f;
     float bDivAvg = 0.75f / a;     // Vector256.Create(b / avgdl), Bm25Scorer.cs:390
     if (N) k_doc_norm<<<(N + 255) / 256, 256>>>(dLen, dNorm, (int)N, bDivAvg);
     HIPCHK(hipDeviceSynchronize());
-    hipFree(dLen);
     if (text_offs && text) {
         uint64_t tot = text_offs[N];
         HIPCHK(dalloc(ix, &dTO, (size_t)N + 1)); HIPCHK(dalloc(ix, &dTx, (size_t)tot));
@@ -404,7 +445,7 @@ int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float
         int R = N >= (4u << 20) ? 8192 : N >= (1u << 20) ? 4096 : N >= (1u << 18) ? 2048 : 1024;
         ix->d.R = R; ix->d.rshift = __builtin_ctz(R);
     }
-    ix->d.N = (int32_t)N; ix->d.docNorm = dNorm; ix->d.docKey = dKey; if (!ix->d.docKeyAll) ix->d.docKeyAll = dKey; ix->d.textOff = dTO; ix->d.text = dTx;
+    ix->d.N = (int32_t)N; ix->d.docNorm = dNorm; ix->d.docLen = dLen; ix->d.docKey = dKey; if (!ix->d.docKeyAll) ix->d.docKeyAll = dKey; ix->d.textOff = dTO; ix->d.text = dTx;
     ix->d.nRanges = (int32_t)(((uint64_t)N + ix->d.R - 1) >> ix->d.rshift);
     if (ix->d.nRanges == 0) ix->d.nRanges = 1;
     if (ix->d.totalDocs == 0) ix->d.totalDocs = (int32_t)N;
@@ -426,7 +467,8 @@ int32_t infx_upload_postings(infx_index* ix, uint32_t T, const uint64_t* offs, c
     HIPCHK(hipMemcpy(dOff, off2.data(), ((size_t)T + 1) * 8, hipMemcpyHostToDevice));
     // packed postings: (doc << 8) | tf in one word — the tf of a candidate posting needs no second (gather) access and a posting costs 4 B
     // instead of 5 B of traffic; possible while shard-local doc ids stay below 2^24 - 1 (sentinel 0xFFFFFFFF decodes to doc 2^24 - 1)
-    ix->d.packed = ((uint64_t)ix->d.N < 0xFFFFFEull && !getenv("INFX_UNPACKED")) ? 1 : 0;
+    // (every doc id a range boundary can name must stay below the sentinel's doc field, so the padded range count is what matters)
+    ix->d.packed = ((uint64_t)ix->d.nRanges * (uint64_t)ix->d.R <= 0xFFFFFFull && !getenv("INFX_UNPACKED")) ? 1 : 0;
     HIPCHK(hipMemset(dDoc, ix->d.packed ? 0xFF : 0x7F, ((size_t)P2 + 4) * 4)); HIPCHK(hipMemset(dW, 0, (size_t)P2 + 4));
     if (P) {
         uint64_t* tOff = nullptr; int32_t* tDoc = nullptr; uint8_t* tW = nullptr;
@@ -467,6 +509,7 @@ int32_t infx_upload_postings(infx_index* ix, uint32_t T, const uint64_t* offs, c
         HIPCHK(hipDeviceSynchronize());
         hipFree(dSkipTerms);
     }
+    ix->hSkipIdx = std::move(skipIdx);
     ix->d.T = (int32_t)T; ix->d.postOff = dOff; ix->d.postDoc = dDoc; ix->d.postW = dW; ix->d.skipIdx = dSkipIdx; ix->d.skipTbl = dSkipTbl;
     ix->havePostings = true;
     return INFX_OK;
@@ -520,6 +563,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     HIPCHK(hipEventCreateWithFlags(&s->evSync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
     HIPCHK(hipMalloc((void**)&s->dStats, 32)); HIPCHK(hipMemset(s->dStats, 0, 32));
+    HIPCHK(hipMalloc((void**)&s->dExactStat, 16)); HIPCHK(hipMemset(s->dExactStat, 0, 16));
     *out = s; return INFX_OK;
 }
 void infx_stream_destroy(infx_stream* s) {
@@ -527,7 +571,7 @@ void infx_stream_destroy(infx_stream* s) {
     hipSetDevice(s->ix->cfg.device);
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
-                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs};
+                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dRefTerms, s->dExactFlag, s->dExactStat};
     for (void* p : ps) if (p) hipFree(p);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
@@ -548,8 +592,10 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     // term ids) is expanded into one device entry per member, all sharing the term's idf / role / rank and a dedupe group.
     std::vector<DevQuery> dq(nq); std::vector<DevTerm> dt; dt.reserve(nterms + 64);
     std::vector<int32_t> termOfEntry; termOfEntry.reserve(nterms + 64);
+    std::vector<DevRefTerm> refT(std::max<uint32_t>(1, nterms));
+    for (uint32_t k = 0; k < nterms; k++) refT[k] = DevRefTerm{terms[k].idf, terms[k].max_score, terms[k].term_id, terms[k].term_id < 0 ? 1u : 0u};
     std::vector<unsigned long long> qbase((size_t)nq + 1);
-    unsigned long long bound = 0; int maxT = 1, useGrp = 0;
+    unsigned long long bound = 0; int maxT = 1, useGrp = 0, maxRef = 0;
     for (uint32_t i = 0; i < nq; i++) {
         const infx_query& Q = q[i];
         if (Q.num_terms > INFX_MAX_QUERY_TERMS || (uint64_t)Q.term_off + Q.num_terms > nterms) return fail(INFX_EINVAL, "bad term range%s");
@@ -562,7 +608,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
             const infx_term& tm = terms[Q.term_off + k];
             const bool gen = (Q.mode == INFX_MODE_AND && (tm.role & (INFX_ROLE_S1 | INFX_ROLE_S2))) ||
                              (Q.mode == INFX_MODE_DISJ && (tm.role & (INFX_ROLE_ELIGIBLE | INFX_ROLE_LOWQ)));
-            DevTerm D{}; D.idf = tm.idf; D.role = tm.role; D.rank = tm.rank; D.pad = 0;
+            DevTerm D{}; D.idf = tm.idf; D.role = tm.role; D.rank = tm.rank; D.pad = 0; D.refIdx = (uint16_t)k; D.pad2 = 0;
             if (tm.term_id >= 0) {
                 if (tm.term_id >= ix->d.T) return fail(INFX_EINVAL, "term id out of range%s");
                 D.begin = ix->hPostOff[tm.term_id]; D.end = D.begin + ix->hPostLen[tm.term_id]; D.isVirtual = 0;
@@ -594,8 +640,8 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
         }
         const uint32_t nEntries = (uint32_t)dt.size() - entryOff;
         if (nEntries > 2048) return fail(INFX_ECAPACITY, "query expands to more than 2048 posting lists (fuzzy member lists); materialise the union on the host%s");
-        dq[i] = DevQuery{entryOff, nEntries, Q.mode, Q.prefix_set, Q.depth, Q.n_and};
-        maxT = std::max(maxT, (int)nEntries);
+        dq[i] = DevQuery{entryOff, nEntries, Q.mode, Q.prefix_set, Q.depth, Q.n_and, Q.term_off, Q.num_terms};
+        maxT = std::max(maxT, (int)nEntries); maxRef = std::max(maxRef, (int)Q.num_terms);
         if (Q.mode == INFX_MODE_PREFIX) qb = ix->hPsOff[Q.prefix_set + 1] - ix->hPsOff[Q.prefix_set];
         qbase[i] = bound;
         bound += std::min<unsigned long long>(qb, (unsigned long long)ix->d.N);
@@ -611,6 +657,17 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
             return fail(INFX_ENOMEM, "arena allocation failed%s");
         s->arCap = n;
     }
+    // per-row hit masks (2 bits per reference term) for the exact Stage-1 replay: kept when every query of the batch has <= 64 terms
+    s->maskWords = !exact_enabled(ix) ? 0 : (maxRef <= 32 ? 1 : (maxRef <= 64 ? 2 : 0));
+    if (s->maskWords && s->arCap * (size_t)s->maskWords > s->arMaskCap) {
+        if (s->arMask) { hipFree(s->arMask); s->arMask = nullptr; s->arMaskCap = 0; }
+        const size_t n = s->arCap * (size_t)s->maskWords;
+        if (hipMalloc((void**)&s->arMask, n * 8) != hipSuccess) return fail(INFX_ENOMEM, "arena mask allocation failed%s");
+        s->arMaskCap = n;
+    }
+    GROW(s->dDir, s->capDir, (size_t)nq * ix->d.nRanges * sizeof(uint2));
+    GROW(s->dRefTerms, s->capRefTerms, refT.size() * sizeof(DevRefTerm));
+    GROW(s->dExactFlag, s->capExactFlag, (size_t)nq * 4);
     GROW(s->dQueries, s->capQueries, nq * sizeof(DevQuery));
     GROW(s->dTerms, s->capTerms, std::max<size_t>(1, dt.size()) * sizeof(DevTerm));
     GROW(s->dExtra, s->capExtra, ((size_t)extra_n + 4) * 4);
@@ -619,30 +676,20 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * 4);        // qCursor
     GROW(s->dQBytes, s->capQBytes, (size_t)nq * 8);
     GROW(s->dCounts, s->capCounts, (size_t)nq * INFX_NCLASS * 4);
-    // skip bases need the device skipIdx: fetch once per index into a host mirror
-    static std::mutex mu; static std::vector<std::pair<infx_index*, std::vector<uint32_t>>> mirrors;
-    const std::vector<uint32_t>* skipMirror = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto& m : mirrors) if (m.first == ix && (int32_t)m.second.size() == ix->d.T) skipMirror = &m.second;
-        if (!skipMirror) {
-            std::vector<uint32_t> v((size_t)ix->d.T);
-            if (ix->d.T) HIPCHK(hipMemcpy(v.data(), ix->d.skipIdx, (size_t)ix->d.T * 4, hipMemcpyDeviceToHost));
-            mirrors.emplace_back(ix, std::move(v)); skipMirror = &mirrors.back().second;
-        }
-    }
-    for (size_t i = 0; i < dt.size(); i++) if (termOfEntry[i] >= 0) dt[i].skip = (*skipMirror)[termOfEntry[i]];
+    for (size_t i = 0; i < dt.size(); i++) if (termOfEntry[i] >= 0) dt[i].skip = ix->hSkipIdx[termOfEntry[i]];
 
     UP(s->dQueries, dq.data(), nq * sizeof(DevQuery));
     UP(s->dTerms, dt.data(), dt.size() * sizeof(DevTerm));
+    UP(s->dRefTerms, refT.data(), refT.size() * sizeof(DevRefTerm));
+    HIPCHK(hipMemsetAsync(s->dExactFlag, 0, (size_t)nq * 4, s->st));
     UP(s->dExtra, extra_docs, (size_t)extra_n * 4);
     UP(s->dBlockOut, qbase.data(), ((size_t)nq + 1) * 8);
     HIPCHK(hipMemsetAsync(s->dQBytes, 0, (size_t)nq * 8, s->st));
     HIPCHK(hipMemsetAsync(s->dOverflow, 0, 4, s->st));
     HIPCHK(hipMemsetAsync(s->dCounts, 0, (size_t)nq * INFX_NCLASS * 4, s->st));
     HIPCHK(hipMemsetAsync(s->dBlockOutHi, 0, (size_t)nq * 4, s->st));
-    Arena ar{s->arDoc, s->arScore, s->arCls, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
-             (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes};
+    HIPCHK(hipMemsetAsync(s->dDir, 0, (size_t)nq * ix->d.nRanges * sizeof(uint2), s->st));
+    Arena ar = make_arena(s);
     HIPCHK(hipEventRecord(s->evA0, s->st));
     switch (ix->d.R) {
         case 512: launch_acc<512>(s, nq, ar, maxT, useGrp); break;
@@ -655,7 +702,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evA1, s->st));
     s->timedAcc = true;
-    s->lastQ.assign(q, q + nq); s->lastNq = nq;
+    s->lastQ.assign(q, q + nq); s->lastNq = nq; s->lastExact = 0;
     return INFX_OK;
 }
 
@@ -694,10 +741,11 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     GROW(s->dHits, s->capHits, (size_t)nq * maxDepth * sizeof(infx_hit));
     GROW(s->dHitCount, s->capHitCount, (size_t)nq * 4);
     UP(s->dRules, rules.data(), nq * sizeof(SelRule));
-    Arena ar{s->arDoc, s->arScore, s->arCls, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
-             (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes};
+    Arena ar = make_arena(s);
     HIPCHK(hipEventRecord(s->evS0, s->st));
-    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth);
+    const bool exact = exact_possible(s);
+    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr);
+    if (exact) { int32_t rc_ = enqueue_exact(s, nq, maxDepth); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evS1, s->st));
     s->timedSel = true;
@@ -794,12 +842,13 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth) 
     GROW(s->dFQueries, s->capFQueries, std::max<size_t>(1, nd) * sizeof(infx_query));
     UP(s->dFQueries, s->lastQ.data(), (size_t)nd * sizeof(infx_query));
     HIPCHK(hipMemsetAsync(s->dHitCount, 0, std::max<size_t>(1, nd) * 4, s->st));
-    Arena ar{s->arDoc, s->arScore, s->arCls, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
-             (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes};
+    Arena ar = make_arena(s);
     HIPCHK(hipEventRecord(s->evS0, s->st));
     if (nd) {
         k_rules<<<(nd + 255) / 256, 256, 0, s->st>>>((const infx_query*)s->dFQueries, (const uint32_t*)s->dCounts, (SelRule*)s->dRules, nd);
-        k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth);
+        const bool exact = exact_possible(s);
+        k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr);
+        if (exact) { int32_t rc_ = enqueue_exact(s, nd, depth); if (rc_) return rc_; }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evS1, s->st));
@@ -1088,6 +1137,10 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, (const unsigned long long*)s->dUBase, (int32_t*)s->dUDocs);
     HIPCHK(hipGetLastError());
     return INFX_OK;     // the write pass stays queued on the stream; infx_stage1_accumulate is ordered behind it
+}
+int32_t infx_last_exact_replays(infx_stream* s, uint32_t* n) {
+    if (!s || !n) return fail(INFX_EINVAL, "null argument%s");
+    *n = s->lastExact; return INFX_OK;
 }
 int32_t infx_last_candidates(infx_stream* s, uint64_t* n) {
     if (!s || !n) return fail(INFX_EINVAL, "null argument%s");

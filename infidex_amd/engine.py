@@ -69,7 +69,7 @@ class Result:      # Api/Result.cs
 class _Cfg(C.Structure):
     _fields_ = [("device", C.c_int32), ("range_docs", C.c_int32), ("max_depth", C.c_int32), ("threads", C.c_int32),
                 ("enable_coverage", C.c_int32), ("word_matcher", C.c_int32), ("stop_term_limit", C.c_int32),
-                ("want_features", C.c_int32)]
+                ("want_features", C.c_int32), ("no_exact_replay", C.c_int32)]
 
 
 _lib = None
@@ -109,9 +109,9 @@ def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
 
 class SearchEngine:
     def __init__(self, enable_coverage=True, word_matcher=True, device: int = 0, range_docs: int = 0, max_depth: int = 500,
-                 threads: int = 0, stop_term_limit: int = 0, want_features: bool = False):
+                 threads: int = 0, stop_term_limit: int = 0, want_features: bool = False, exact_replay: bool = True):
         self.L = load_library()
-        cfg = _Cfg(device, range_docs, max_depth, threads, int(enable_coverage), int(word_matcher), stop_term_limit, int(want_features))
+        cfg = _Cfg(device, range_docs, max_depth, threads, int(enable_coverage), int(word_matcher), stop_term_limit, int(want_features), int(not exact_replay))
         h = C.c_void_p()
         self._check(self.L.infx_engine_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -195,13 +195,13 @@ class SearchEngine:
         return out
 
     def last_timings(self):
-        host = np.zeros(5, np.float64); kern = np.zeros(5, np.float32); alg = np.zeros(5, np.uint64)
+        host = np.zeros(5, np.float64); kern = np.zeros(5, np.float32); alg = np.zeros(6, np.uint64)
         self._check(self.L.infx_engine_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))
         return {"plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
                 "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
                 "k_prep2_ms": float(kern[3]), "k_finalize_ms": float(kern[4]),
                 "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2]),
-                "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4])}
+                "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4]), "exact_replays": int(alg[5])}
 
     # ---- introspection (parity tests) ----
     def index_stats(self):
@@ -256,6 +256,10 @@ class SearchEngine:
         a = _u16(p)
         return int(self.L.infx_engine_prefix_pop(self.h, _p(a, C.c_uint16), len(a)))
 
+    def set_introspection(self, on=True):
+        """Parity tooling: keep the Stage-1 rows / Stage-2 candidates of the last batch for last_stage1() / last_stage2()."""
+        self._check(self.L.infx_engine_set_introspection(self.h, int(bool(on))))
+
     def last_stage1(self, qi, cap=4096):
         keys = np.zeros(cap, np.int64); sc = np.zeros(cap, np.float32)
         n = self.L.infx_engine_last_stage1(self.h, qi, _p(keys, C.c_int64), _p(sc, C.c_float), cap)
@@ -303,13 +307,13 @@ class Session:
         return keys, scores, ties, counts, flags
 
     def last_timings(self):
-        host = np.zeros(5, np.float64); kern = np.zeros(5, np.float32); alg = np.zeros(5, np.uint64)
+        host = np.zeros(5, np.float64); kern = np.zeros(5, np.float32); alg = np.zeros(6, np.uint64)
         self.engine._check(self.L.infx_engine_session_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))
         return {"plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
                 "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
                 "k_prep2_ms": float(kern[3]), "k_finalize_ms": float(kern[4]),
                 "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2]),
-                "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4])}
+                "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4]), "exact_replays": int(alg[5])}
 
 
 def normalize(s, lower=False):

@@ -213,6 +213,7 @@ class ShardedSearcher:
             # RCCL path: the hit lists and the Stage-2 rows stay in HBM; the collectives run on the tensors the kernels wrote
             torch = c.torch; nd = max(s.nd, 1); nq = s.nq
             hits_t = torch.zeros((nd, depth, 2), dtype=torch.int32, device=c.device); hc_t = torch.zeros(nd, dtype=torch.int32, device=c.device)
+            torch.cuda.current_stream().synchronize()      # the zero fills run on torch's stream, the engine writes on its own: order them
             mark(); s.phase2_dev(gcounts, hits_t, hc_t); mark()
             all_hits_t = torch.empty((c.world, nd, depth, 2), dtype=torch.int32, device=c.device)
             all_hc_t = torch.empty((c.world, nd), dtype=torch.int32, device=c.device)
@@ -251,6 +252,7 @@ def simulate_shards_dev(sessions: Sequence[ShardSession], arena, offs, max_resul
     hits, hcs = [], []
     for s in sessions:
         h = torch.zeros((nd, depth, 2), dtype=torch.int32, device=device); c = torch.zeros(nd, dtype=torch.int32, device=device)
+        torch.cuda.synchronize()                            # zero fills (torch stream) before the engine's writes (its own stream)
         s.phase2_dev(g, h, c); hits.append(h); hcs.append(c)
     all_hits = torch.stack(hits).contiguous(); all_hc = torch.stack(hcs).contiguous()
     outs = []

@@ -1,0 +1,39 @@
+"""Classification of a query whose final top-k DocumentId set differs between the HIP path and the oracle.
+
+Used by tests/test_gpu_scale.py and by bench.py's reported set comparison.  A difference is a "tie-at-cut-off" only if the Stage-1
+top-`depth` sets differ and every document in their symmetric difference scores within SCORE_RTOL*4 of the oracle's cut-off score
+(the reference's own arithmetic is position dependent there: quirk Q9 + the BCL heap order).  Anything else is
+"other" and is a parity failure.
+"""
+import numpy as np
+
+SCORE_RTOL = 2e-6 * 32
+
+
+def classify(engine, oracle, queries, k, depth=500):
+    """queries: texts whose final sets differ.  Returns a list of dicts {query, kind, detail}."""
+    out = []
+    engine.set_introspection(True)
+    try:
+        for q in queries:
+            res = engine.search_batch([q], k, depth)[0]
+            r = oracle.search(q, k, depth)
+            ok, osc = oracle.last_stage1()
+            gk, gsc = engine.last_stage1(0)
+            od = dict(zip(ok.tolist(), osc.tolist())); gd = dict(zip(gk.tolist(), gsc.tolist()))
+            got = [x.document_id for x in res.records]
+            if set(got) == set(r["keys"]):
+                out.append({"query": q, "kind": "identical-on-rerun", "detail": ""})
+                continue
+            sym = set(od) ^ set(gd)
+            cut = min(osc) if len(osc) else 0.0
+            if sym and all(abs(od.get(d, gd.get(d)) - cut) <= SCORE_RTOL * 4 * max(abs(cut), 1.0) for d in sym):
+                exact = sum(1 for d in sym if np.float32(od.get(d, gd.get(d))) == np.float32(cut))
+                out.append({"query": q, "kind": "tie-at-cut-off",
+                            "detail": f"stage-1 symmetric difference {len(sym)} docs at cut {cut!r} ({exact} bit-equal to it); final diff {sorted(set(got) ^ set(r['keys']))}"})
+            else:
+                out.append({"query": q, "kind": "other",
+                            "detail": f"stage-1 symmetric difference {len(sym)} docs, cut {cut!r}; final got {got} want {r['keys']}"})
+    finally:
+        engine.set_introspection(False)
+    return out

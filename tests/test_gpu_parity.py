@@ -73,7 +73,7 @@ def compare_batch(e, o, queries, k, depth=500, check_features=True):
     for i in range(len(qo)):
         order.setdefault(int(qo[i]), []).append(i)
     cov_idx = 0
-    stats = dict(n=0, set_mismatch=0, order_mismatch=0, feat_mismatch=0, s1_boundary=0, max_s1_rel=0.0, max_final_abs=0.0)
+    stats = dict(n=0, set_mismatch=0, order_mismatch=0, feat_mismatch=0, s1_boundary=0, s1_bitexact=0, max_s1_rel=0.0, max_final_abs=0.0)
     for qi, q in enumerate(queries):
         r = o.search(q, k, depth)
         got = res[qi]
@@ -87,6 +87,8 @@ def compare_batch(e, o, queries, k, depth=500, check_features=True):
             rel = abs(od[key] - gd[key]) / max(abs(od[key]), 1e-9)
             stats["max_s1_rel"] = max(stats["max_s1_rel"], rel)
             assert rel <= SCORE_RTOL, (q, key, od[key], gd[key])
+        if set(od) == set(gd) and all(np.float32(od[key]) == np.float32(gd[key]) for key in od):
+            stats["s1_bitexact"] += 1
         if set(od) != set(gd):
             # allowed only at the cut-off: every doc in the symmetric difference scores within tolerance of the k-th score
             cut = min(osc) if len(osc) else 0.0
@@ -157,6 +159,7 @@ def test_synthetic_parity(synth_pair):
     print("parity stats", st)
     assert st["feat_mismatch"] == 0
     assert st["set_mismatch"] == 0, st      # identical top-k DocumentId sets
+    assert st["s1_boundary"] == 0, st       # exact replay: the Stage-1 top-`depth` SET is the oracle's for every query, ties included
     assert st["order_mismatch"] <= st["n"] * 0.02, st   # order may flip only between 2^-6-quantised near-ties
 
 
@@ -178,7 +181,7 @@ def test_sharded_equals_unsharded():
     from infidex_amd.engine import pack_texts
     s = Synth(2, docs=30000)
     arena, offs = s.docs()
-    ref = SearchEngine.create_default(device=0); ref.index_flat(None, arena, offs, s.field_weights)
+    ref = SearchEngine.create_default(device=0, exact_replay=False); ref.index_flat(None, arena, offs, s.field_weights)   # shards cut ties by (score, doc id)
     W = 3
     engs = [create_sharded_engine(r, W, 0) for r in range(W)]
     for e in engs:
