@@ -253,7 +253,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": acc_ms,
                      "streamed_bytes_per_launch": streamed, "stage1_candidates_per_launch": float(np.mean([t["stage1_candidates"] for t in roof])),
-                     "stage2_rows_per_launch": float(np.mean([t["stage2_candidates"] for t in roof])), "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
+                     "stage2_rows_per_launch": float(np.mean([t["stage2_candidates"] for t in roof])), "exact_replays_per_launch": float(np.mean([t["exact_replays"] for t in roof])), "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
                      "other_kernels_ms": {kk: float(np.mean([t[kk + "_ms"] for t in roof])) for kk in ("k_select", "k_prep2", "k_stage2", "k_finalize")},
                      "note": "achieved = SURVEY 8(d) algorithmic bytes / k_accumulate duration (HIP events, uncontended launch); ranges without "
                              "candidates are skipped, so fewer bytes are streamed than the algorithm nominally reads"},

@@ -157,6 +157,7 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 
 #include "stage1.hip.inc"
 #include "exact1.hip.inc"
+#include "exact3.hip.inc"
 #include "stage2.hip.inc"
 
 // TieredCandidateSelector tier rules evaluated from class counts (see header of this file / DESIGN.md)
@@ -237,9 +238,12 @@ struct infx_stream {
     void* dCovF = nullptr; size_t capCovF = 0;
     int32_t* arDoc = nullptr; float* arScore = nullptr; uint8_t* arCls = nullptr; size_t arCap = 0;
     unsigned long long* arMask = nullptr; size_t arMaskCap = 0; int maskWords = 0;     // per-row hit masks of the last accumulate launch
+    uint32_t* arExc = nullptr; uint32_t* exCand = nullptr; infx_hit* exOut = nullptr; size_t exCap = 0;       // tf exception records, candidate lists, replay rows (arena-sized)
+    void* exChunks = nullptr; size_t capExChunks = 0; void* exQueries = nullptr; size_t capExQueries = 0; void* exTasks = nullptr; size_t capExTasks = 0; uint32_t* exCounters = nullptr;
+    uint32_t exChunkCap = 0; size_t arBound = 0;
     void* dDir = nullptr; size_t capDir = 0;
     void* dRefTerms = nullptr; size_t capRefTerms = 0; void* dExactFlag = nullptr; size_t capExactFlag = 0; uint32_t* dExactStat = nullptr;   // k_exact1 inputs
-    uint32_t lastExact = 0;                                                              // queries replayed exactly in the last batch                                            // (query, range) chunk directory
+    uint32_t lastExact2[2] = {0, 0};                                                     // last batch: queries replayed exactly, of them by the sequential fallback                                            // (query, range) chunk directory
     unsigned long long* dCursor = nullptr;   // [0]=cursor [1]=algBytes
     uint32_t* dOverflow = nullptr;
     std::vector<infx_query> lastQ;            // kept between accumulate and select
@@ -356,7 +360,7 @@ static void launch_union_any(infx_stream* s, uint32_t nv, const uint32_t* dOffs,
 // exact replay of the reference's Stage-1 order effects (k_exact1) — on unless INFX_EXACT=0
 static bool exact_enabled(const infx_index* ix) { static const bool v = [] { const char* e = getenv("INFX_EXACT"); return !(e && e[0] == '0'); }(); return v && !(ix->cfg.flags & INFX_CFG_NO_EXACT_REPLAY); }
 static Arena make_arena(infx_stream* s) {
-    return Arena{s->arDoc, s->arScore, s->arCls, s->arMask, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
+    return Arena{s->arDoc, s->arScore, s->arCls, s->arMask, s->arExc, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
                  (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes, (uint2*)s->dDir, s->maskWords};
 }
 static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX_ACC_STRIPE"); int x = e ? atoi(e) : 0; return (x >= 1 && x <= 64) ? x : 4; }(); return v; }
@@ -381,16 +385,36 @@ static bool exact_possible(infx_stream* s) { return exact_enabled(s->ix) && s->m
 static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
     infx_index* ix = s->ix;
     const int MW = s->maskWords, depthCap = ix->cfg.max_depth;
-    const size_t lds = (size_t)(EX_CHUNK + EX_THREADS) * MW * 8 + (size_t)(EX_CHUNK + EX_THREADS) * 4 + (size_t)EX_CHUNK * 4 + (size_t)depthCap * 8 +
-                       (INFX_MAX_QUERY_TERMS + 1) * 4 + 130 * 4 + 129 * 4 + 8 * 4 + (size_t)EX_CHUNK * 2 + 64;
-    static std::mutex mu; static size_t attrSet = 0;
-    { std::lock_guard<std::mutex> lk(mu); if (lds > attrSet) { HIPCHK(hipFuncSetAttribute((const void*)k_exact1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; } }
+    static const bool slowOnly = [] { const char* e = getenv("INFX_EXACT_SLOW"); return e && e[0] == '1'; }();      // parity tooling: k_exact1 for every flagged query
+    const size_t lds1 = (size_t)(EX_CHUNK + EX_THREADS) * MW * 8 + (size_t)(EX_CHUNK + EX_THREADS) * 4 + (size_t)EX_CHUNK * 4 + (size_t)depthCap * 8 +
+                        (INFX_MAX_QUERY_TERMS + 1) * 4 + 130 * 4 + 129 * 4 + 8 * 4 + (size_t)EX_CHUNK * 2 + 64;
+    static std::mutex mu; static size_t attr1 = 0;
+    { std::lock_guard<std::mutex> lk(mu);
+      if (lds1 > attr1) { HIPCHK(hipFuncSetAttribute((const void*)k_exact1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); attr1 = lds1; } }
     Arena ar = make_arena(s);
-    HIPCHK(hipMemsetAsync(s->dExactStat, 0, 4, s->st));
-    k_exact1<<<nq, EX_THREADS, lds, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag,
-                                             ix->avgdl, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, depthCap, s->dExactStat);
+    HIPCHK(hipMemsetAsync(s->dExactStat, 0, 16, s->st));
+    const bool fast = !slowOnly && depthCap <= EXS_MAXDEPTH;
+    if (fast) {
+        // chunk table: every query needs at most (containers + reserved rows / 4096 + 2) entries
+        const int rpc = 65536 / ix->d.R, nCont = (ix->d.nRanges + rpc - 1) / rpc;
+        const size_t cap = (size_t)nq * (nCont + 2) + s->arBound / EX_CHUNK + 16;
+        if (cap > 0x7FFFFFF0ull) return fail(INFX_ECAPACITY, "exact-replay chunk table too large; split the batch%s");
+        GROW(s->exChunks, s->capExChunks, cap * sizeof(ExChunk));
+        GROW(s->exTasks, s->capExTasks, cap * 2 * 4);
+        GROW(s->exQueries, s->capExQueries, (size_t)nq * sizeof(ExQuery));
+        s->exChunkCap = (uint32_t)cap;
+        HIPCHK(hipMemsetAsync(s->exCounters, 0, 16, s->st));
+        ExBufs xb{s->exCand, s->exOut, s->arExc, (ExChunk*)s->exChunks, s->exChunkCap, (ExQuery*)s->exQueries, s->exCounters, (uint32_t*)s->exTasks, (uint32_t*)s->exTasks + cap};
+        k_ex_scan<<<nq, EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb);
+        k_ex_chunk<EXC_SMALL><<<8192, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksSmall, 1, ix->avgdl);
+        k_ex_chunk<EXC_BIG><<<2048, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 2, ix->avgdl);
+        k_ex_heap<<<nq, WAVE, 0, s->st>>>(ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, s->dExactStat);
+        HIPCHK(hipGetLastError());
+    }
+    k_exact1<<<nq, EX_THREADS, lds1, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag,
+                                             fast ? 2u : 1u, ix->avgdl, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, depthCap, s->dExactStat);
     HIPCHK(hipGetLastError());
-    DOWN(&s->lastExact, s->dExactStat, 4);          // lands at the caller's stream synchronisation
+    DOWN(s->lastExact2, s->dExactStat, 8);          // [0] replayed queries, [1] of them through the sequential k_exact1 fallback; lands at the caller's synchronisation
     return INFX_OK;
 }
 
@@ -562,8 +586,9 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     for (auto e : ev) HIPCHK(hipEventCreate(e));
     HIPCHK(hipEventCreateWithFlags(&s->evSync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
-    HIPCHK(hipMalloc((void**)&s->dStats, 32)); HIPCHK(hipMemset(s->dStats, 0, 32));
+    HIPCHK(hipMalloc((void**)&s->dStats, 64)); HIPCHK(hipMemset(s->dStats, 0, 64));
     HIPCHK(hipMalloc((void**)&s->dExactStat, 16)); HIPCHK(hipMemset(s->dExactStat, 0, 16));
+    HIPCHK(hipMalloc((void**)&s->exCounters, 16)); HIPCHK(hipMemset(s->exCounters, 0, 16));
     *out = s; return INFX_OK;
 }
 void infx_stream_destroy(infx_stream* s) {
@@ -571,7 +596,7 @@ void infx_stream_destroy(infx_stream* s) {
     hipSetDevice(s->ix->cfg.device);
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
-                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dRefTerms, s->dExactFlag, s->dExactStat};
+                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters};
     for (void* p : ps) if (p) hipFree(p);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
@@ -665,6 +690,13 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
         if (hipMalloc((void**)&s->arMask, n * 8) != hipSuccess) return fail(INFX_ENOMEM, "arena mask allocation failed%s");
         s->arMaskCap = n;
     }
+    if (s->maskWords && s->arCap > s->exCap) {
+        if (s->arExc) { hipFree(s->arExc); hipFree(s->exCand); hipFree(s->exOut); s->arExc = nullptr; s->exCand = nullptr; s->exOut = nullptr; s->exCap = 0; }
+        if (hipMalloc((void**)&s->arExc, s->arCap * 4) != hipSuccess || hipMalloc((void**)&s->exCand, s->arCap * 4) != hipSuccess || hipMalloc((void**)&s->exOut, s->arCap * sizeof(infx_hit)) != hipSuccess)
+            return fail(INFX_ENOMEM, "exact-replay workspace allocation failed%s");
+        s->exCap = s->arCap;
+    }
+    s->arBound = (size_t)bound;
     GROW(s->dDir, s->capDir, (size_t)nq * ix->d.nRanges * sizeof(uint2));
     GROW(s->dRefTerms, s->capRefTerms, refT.size() * sizeof(DevRefTerm));
     GROW(s->dExactFlag, s->capExactFlag, (size_t)nq * 4);
@@ -702,7 +734,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evA1, s->st));
     s->timedAcc = true;
-    s->lastQ.assign(q, q + nq); s->lastNq = nq; s->lastExact = 0;
+    s->lastQ.assign(q, q + nq); s->lastNq = nq; s->lastExact2[0] = s->lastExact2[1] = 0;
     return INFX_OK;
 }
 
@@ -1140,7 +1172,7 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
 }
 int32_t infx_last_exact_replays(infx_stream* s, uint32_t* n) {
     if (!s || !n) return fail(INFX_EINVAL, "null argument%s");
-    *n = s->lastExact; return INFX_OK;
+    *n = s->lastExact2[0] + s->lastExact2[1]; return INFX_OK;
 }
 int32_t infx_last_candidates(infx_stream* s, uint64_t* n) {
     if (!s || !n) return fail(INFX_EINVAL, "null argument%s");

@@ -199,3 +199,43 @@ def test_concurrent_sessions_match_sequential_results(corpus):
     for g, x in zip(got, expect):
         for u, v in zip(g, x):
             assert np.array_equal(u, v)
+
+
+def test_parallel_exact_replay_equals_the_sequential_kernel(tmp_path):
+    """The production replay (k_ex_scan / k_ex_chunk / k_ex_heap) and the literal sequential kernel (k_exact1, INFX_EXACT_SLOW=1) are two
+    implementations of the same reference semantics: final rows AND the Stage-1 rows (sets, fp32 score bits) must be identical."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np
+from infidex_amd import SearchEngine
+from infidex_amd.engine import pack_texts
+from tools.synth import Synth
+s = Synth(4, docs=300000); arena, offs = s.docs()
+e = SearchEngine.create_default(device=0, want_features=True); e.index_flat(None, arena, offs, s.field_weights)
+qa, qo = s.queries(400, qseed=77)
+texts = Synth.texts(qa, qo)
+a, o = pack_texts(texts)
+k, sc, t, c, f = e.search_packed(a, o, 20)
+s1k = []; s1s = []
+for i in range(len(texts)):
+    kk, ss = e.last_stage1(i)
+    s1k.append(np.asarray(kk, np.int64)); s1s.append(np.asarray(ss, np.float32))
+n = e.last_timings()["exact_replays"]
+np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f, s1k=np.concatenate(s1k), s1s=np.concatenate(s1s), s1n=np.asarray([len(x) for x in s1k]), replays=n)
+'''
+    outs = []
+    for slow in ("0", "1"):
+        env = dict(os.environ); env.pop("INFX_EXACT_SLOW", None)
+        if slow == "1":
+            env["INFX_EXACT_SLOW"] = "1"
+        env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = str(tmp_path / f"x{slow}.npz")
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=env, timeout=900)
+        outs.append(np.load(path))
+    a, b = outs
+    print("exact replays:", int(a["replays"]), int(b["replays"]))
+    assert int(a["replays"]) > 20 and int(a["replays"]) == int(b["replays"])
+    for key in ("k", "sc", "t", "c", "f", "s1n", "s1k"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(a["s1s"].view(np.uint32), b["s1s"].view(np.uint32))
