@@ -367,7 +367,7 @@ static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp) {
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
     const int stripe = acc_stripe();
-    const size_t lds = (size_t)R + 128 + (size_t)(maxT + 1) * sizeof(TermLds) + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + (size_t)(R / 32) * 2 + ACC_CAP_DEFAULT * 2;   // sized by the batch's longest query
+    const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
     const uint64_t blocks = (uint64_t)nq * ((s->ix->d.nRanges + stripe - 1) / stripe);
     if (ar.maskWords == 2)
         k_accumulate<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
@@ -408,8 +408,13 @@ static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
         k_ex_scan<<<nq, EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb);
         k_ex_chunk<EXC_SMALL><<<8192, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksSmall, 1, ix->avgdl);
         k_ex_chunk<EXC_BIG><<<2048, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 2, ix->avgdl);
-        k_ex_heap<<<nq, WAVE, 0, s->st>>>(ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, s->dExactStat);
+        static const bool exProf = getenv("INFX_EXACT_PROF") != nullptr;     // k_ex_heap counters (profiling only)
+        k_ex_heap<<<nq, WAVE, 0, s->st>>>(ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, s->dExactStat,
+                                          exProf ? (unsigned long long*)s->dStats : nullptr);
         HIPCHK(hipGetLastError());
+        if (exProf) { unsigned long long h[8]; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 64, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 64);
+            if (h[0]) fprintf(stderr, "[infx] k_ex_heap per query over %llu queries: chunks %.0f rows %.0f admitted-or-tested %.0f heap-cycles %.0f total-cycles %.0f\n", h[0],
+                              (double)h[5] / h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0]); }
     }
     k_exact1<<<nq, EX_THREADS, lds1, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag,
                                              fast ? 2u : 1u, ix->avgdl, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, depthCap, s->dExactStat);
