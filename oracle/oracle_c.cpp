@@ -2,6 +2,8 @@
 // C ABI over the CPU restatement so tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can
 // drive it through ctypes. Nothing under infidex_amd/ may link or load this library.
 #include "pipeline.hpp"
+#include "filter.hpp"
+#include <sstream>
 #include <chrono>
 #include <thread>
 #include <atomic>
@@ -24,11 +26,17 @@ void pack_features(const CoverageFeatures& f, int lcs, int32_t* o) {
     o[25] = fbits(f.SumCi); o[26] = fbits(f.IdfCoverage); o[27] = fbits(f.TotalIdf); o[28] = fbits(f.MissingIdf);
     o[29] = fbits(f.LastTermCi); o[30] = fbits(f.WeightedCoverage); o[31] = 0;
 }
+struct Column { std::string name; bool facetable; std::vector<flt::Value> vals; };     // a non-indexed document field (DocumentFields), by internal doc id
 struct Handle {
     Engine eng;
     SearchOutput last;
+    std::vector<Column> cols;
+    std::map<std::string, int> filterCount;       // Filter.NumberOfDocumentsInFilter, computed on first use (ResultProcessor.cs:39-54)
+    std::string lastFacets; int lastInFilter = 0;
     explicit Handle(const Config& c) : eng(c) {}
+    flt::Fields fields_of(int doc) const { flt::Fields f; for (auto& c : cols) if ((size_t)doc < c.vals.size()) f[c.name] = c.vals[doc]; return f; }
 };
+std::string json_escape(const std::string& s) { std::string o; for (char c : s) { if (c == '"' || c == '\\') o.push_back('\\'); o.push_back(c); } return o; }
 }
 
 extern "C" {
@@ -235,5 +243,80 @@ double orc_timed_batch(void* h, int32_t nq, const uint16_t* arena, const uint64_
     else { std::vector<std::thread> th; for (int t = 0; t < threads; t++) th.emplace_back(worker); for (auto& t : th) t.join(); }
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
+
+
+// ---- Infiscript filter / facets (config 5) ------------------------------------------------------------------------------
+// Evaluates `expr` against one document given as parallel field arrays. kinds: 0 null, 1 int64, 2 double, 3 string (UTF-8).
+// Returns 1 / 0, -1 on a parse error, -2 for a construct the oracle does not restate.
+int32_t orc_filter_eval(const char* expr, int32_t nfields, const char* const* names, const int32_t* kinds, const int64_t* ints, const double* dbls, const char* const* strs) {
+    try {
+        flt::Compiled c = flt::compile(flt::parse(expr));
+        flt::Fields f;
+        for (int i = 0; i < nfields; i++) {
+            flt::Value v;
+            if (kinds[i] == 1) v = flt::Value::integer(ints[i]); else if (kinds[i] == 2) v = flt::Value::num(dbls[i]); else if (kinds[i] == 3) v = flt::Value::str(strs[i]);
+            f[names[i]] = v;
+        }
+        return flt::execute(c, f) ? 1 : 0;
+    } catch (const flt::ParseError& e) { return std::string(e.what()).find("not restated") != std::string::npos ? -2 : -1; }
+      catch (const std::exception&) { return -2; }
+}
+int32_t orc_double_to_string(double x, char* out, int32_t cap) { std::string s = flt::dbl_to_string(x); snprintf(out, (size_t)cap, "%s", s.c_str()); return (int32_t)s.size(); }
+// One column of non-indexed document fields, by internal doc id. kind: 1 int64 (vals_i), 2 double (vals_d), 3 string (arena + offs, UTF-8)
+void orc_set_column(void* h, const char* name, int32_t kind, int32_t facetable, int64_t n, const int64_t* vals_i, const double* vals_d, const char* arena, const uint64_t* offs) {
+    Handle* H = (Handle*)h; Column c; c.name = name; c.facetable = facetable != 0; c.vals.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        if (kind == 1) c.vals[i] = flt::Value::integer(vals_i[i]); else if (kind == 2) c.vals[i] = flt::Value::num(vals_d[i]);
+        else c.vals[i] = flt::Value::str(std::string(arena + offs[i], arena + offs[i + 1]));
+    }
+    for (auto& x : H->cols) if (x.name == c.name) { x = c; return; }
+    H->cols.push_back(std::move(c));
+}
+// SearchEngine.Search with Query.Filter / Query.EnableFacets (SearchEngine.cs:298-316): Execute(max) -> ApplyFilter -> facets -> Take(max).
+// filter may be NULL.  Returns the row count, or -1 / -2 as orc_filter_eval.
+int32_t orc_search_filtered(void* h, const uint16_t* q, int32_t qlen, int32_t max_results, int32_t depth, int32_t enable_cov, const char* filter, int32_t enable_facets,
+                            int64_t* keys, float* scores, uint8_t* ties, int32_t cap, int32_t* flags, int32_t* n_in_filter) {
+    Handle* H = (Handle*)h;
+    QueryParams qp; qp.maxResults = max_results; qp.coverageDepth = depth; qp.enableCoverage = enable_cov != 0;
+    H->last = H->eng.search(uview((const u16*)q, qlen), qp);
+    std::vector<ScoreEntry> rows(H->last.records.begin(), H->last.records.end());
+    H->lastInFilter = 0; H->lastFacets = "{}";
+    auto doc_of = [&](int64_t key) -> int { auto it = H->eng.ix.keyToFirstId.find(key); return it == H->eng.ix.keyToFirstId.end() ? -1 : it->second; };
+    if (filter) {
+        flt::Compiled c;
+        try { c = flt::compile(flt::parse(filter)); }
+        catch (const flt::ParseError& e) { return std::string(e.what()).find("not restated") != std::string::npos ? -2 : -1; }
+        auto fc = H->filterCount.find(filter);
+        if (fc == H->filterCount.end() || fc->second == 0) {                 // NumberOfDocumentsInFilter == 0 -> count over ALL documents
+            int m = 0; for (int d = 0; d < H->eng.ix.N; d++) if (flt::execute(c, H->fields_of(d))) m++;
+            H->filterCount[filter] = m;
+        }
+        H->lastInFilter = H->filterCount[filter];
+        std::vector<ScoreEntry> kept;
+        for (auto& r : rows) { int d = doc_of(r.key); if (d < 0) continue; if (flt::execute(c, H->fields_of(d))) kept.push_back(r); }
+        rows.swap(kept);
+    }
+    if (enable_facets && !rows.empty()) {
+        std::vector<flt::Fields> fs; std::vector<const flt::Fields*> ps;
+        for (auto& r : rows) { int d = doc_of(r.key); if (d >= 0) fs.push_back(H->fields_of(d)); }
+        for (auto& f : fs) ps.push_back(&f);
+        std::ostringstream o; o << "{"; bool first = true;
+        for (auto& col : H->cols) if (col.facetable) {
+            auto fc = flt::facet(ps, col.name);
+            if (fc.empty()) continue;
+            if (!first) o << ","; first = false;
+            o << "\"" << json_escape(col.name) << "\":[";
+            for (size_t i = 0; i < fc.size(); i++) { if (i) o << ","; o << "[\"" << json_escape(fc[i].first) << "\"," << fc[i].second << "]"; }
+            o << "]";
+        }
+        o << "}"; H->lastFacets = o.str();
+    }
+    if (n_in_filter) *n_in_filter = H->lastInFilter;
+    int n = std::min<int>(std::min<int>(cap, max_results), (int)rows.size());
+    for (int i = 0; i < n; i++) { keys[i] = rows[i].key; scores[i] = rows[i].score; ties[i] = rows[i].tie; }
+    if (flags) *flags = (H->last.unsupported ? 1 : 0) | (H->last.usedCoverage ? 2 : 0);
+    return n;
+}
+int32_t orc_last_facets_json(void* h, char* out, int32_t cap) { Handle* H = (Handle*)h; snprintf(out, (size_t)cap, "%s", H->lastFacets.c_str()); return (int32_t)H->lastFacets.size(); }
 
 } // extern "C"

@@ -253,3 +253,60 @@ def coverage_standalone(query, doc, lcs_sum=0.0, bm25=0.0, word_idf=None):
                                     _p(feat, C.c_int32), C.byref(score), C.byref(tie),
                                     len(words), _p(warena, C.c_uint16), _p(woffs, C.c_uint64), _p(wvals, C.c_float))
     return cov, dict(zip(FEAT_NAMES, feat.tolist())), score.value, tie.value
+
+
+# ---- Infiscript filter / facets (config 5) ------------------------------------------------------------------------------
+def filter_eval(expr, fields):
+    """fields: dict name -> None | int | float | str.  Returns True / False; raises ValueError on a parse error, NotImplementedError for
+    a construct the oracle does not restate (MATCHES)."""
+    L = lib()
+    names = list(fields.keys())
+    kinds = (C.c_int32 * len(names))(); ints = (C.c_int64 * len(names))(); dbls = (C.c_double * len(names))()
+    cn = (C.c_char_p * len(names))(*[n.encode() for n in names]); cs = (C.c_char_p * len(names))()
+    for i, n in enumerate(names):
+        v = fields[n]
+        if v is None: kinds[i] = 0
+        elif isinstance(v, bool): kinds[i] = 3; cs[i] = (b"True" if v else b"False")
+        elif isinstance(v, int): kinds[i] = 1; ints[i] = v
+        elif isinstance(v, float): kinds[i] = 2; dbls[i] = v
+        else: kinds[i] = 3; cs[i] = str(v).encode()
+    L.orc_filter_eval.restype = C.c_int32
+    r = L.orc_filter_eval(expr.encode(), len(names), cn, kinds, ints, dbls, cs)
+    if r == -1: raise ValueError("FilterParseException: " + expr)
+    if r == -2: raise NotImplementedError(expr)
+    return bool(r)
+
+
+def double_to_string(x):
+    buf = C.create_string_buffer(64); lib().orc_double_to_string(C.c_double(x), buf, 64); return buf.value.decode()
+
+
+def _oe_set_column(self, name, values, facetable=False):
+    """A non-indexed document field per internal doc id: int64 / float64 numpy array or a list of str."""
+    n = len(values)
+    if isinstance(values, np.ndarray) and values.dtype.kind in "iu":
+        v = np.ascontiguousarray(values, np.int64); self.L.orc_set_column(self.h, name.encode(), 1, int(facetable), C.c_int64(n), _p(v, C.c_int64), None, None, None)
+    elif isinstance(values, np.ndarray) and values.dtype.kind == "f":
+        v = np.ascontiguousarray(values, np.float64); self.L.orc_set_column(self.h, name.encode(), 2, int(facetable), C.c_int64(n), None, _p(v, C.c_double), None, None)
+    else:
+        bs = [str(x).encode() for x in values]; offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum([len(b) for b in bs]); arena = b"".join(bs) + b"\0"
+        self.L.orc_set_column(self.h, name.encode(), 3, int(facetable), C.c_int64(n), None, None, C.c_char_p(arena), _p(offs, C.c_uint64))
+
+
+def _oe_search_filtered(self, text, max_results=10, depth=500, enable_coverage=True, filter=None, enable_facets=False):
+    import json
+    q = u16(text); cap = max(max_results, 1)
+    keys = np.zeros(cap, np.int64); scores = np.zeros(cap, np.float32); ties = np.zeros(cap, np.uint8)
+    flags = C.c_int32(0); nin = C.c_int32(0)
+    self.L.orc_search_filtered.restype = C.c_int32
+    n = self.L.orc_search_filtered(self.h, _p(q, C.c_uint16), len(q), max_results, depth, int(enable_coverage), filter.encode() if filter is not None else None,
+                                   int(enable_facets), _p(keys, C.c_int64), _p(scores, C.c_float), _p(ties, C.c_uint8), cap, C.byref(flags), C.byref(nin))
+    if n == -1: raise ValueError("FilterParseException: " + str(filter))
+    if n == -2: raise NotImplementedError(str(filter))
+    buf = C.create_string_buffer(1 << 16); self.L.orc_last_facets_json(self.h, buf, 1 << 16)
+    return {"keys": keys[:n].tolist(), "scores": scores[:n].copy(), "ties": ties[:n].copy(), "used_coverage": bool(flags.value & 2),
+            "in_filter": int(nin.value), "facets": {k: [(a, int(b)) for a, b in v] for k, v in json.loads(buf.value.decode() or "{}").items()}}
+
+
+OracleEngine.set_column = _oe_set_column
+OracleEngine.search_filtered = _oe_search_filtered

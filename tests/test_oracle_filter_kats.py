@@ -1,0 +1,79 @@
+"""The oracle's Infiscript restatement (oracle/filter.hpp) against the reference's own known answers:
+BytecodeVMTests.cs, FilterParserTests.cs, TernaryFilterTests.cs, FilterParserErrorTests.cs, FacetingTests.cs (values restated here)."""
+import pytest
+
+from tests import oracle_lib as O
+
+T, F = True, False
+VM_KATS = [
+    # BytecodeVMTests.cs:64-103 (ValueFilter)
+    ("genre = 'Fantasy'", {"genre": "Fantasy"}, T), ("genre = 'Fantasy'", {"genre": "Horror"}, F), ("genre = 'fantasy'", {"genre": "FANTASY"}, T),
+    # :107-157 (RangeFilter: BETWEEN / min only / max only / out of range)
+    ("year BETWEEN 2000 AND 2020", {"year": 2010}, T), ("year >= 2000", {"year": 2015}, T), ("year <= 2020", {"year": 2015}, T), ("year BETWEEN 2000 AND 2010", {"year": 2020}, F),
+    # :558-609 (parsed filters)
+    ("(genre = 'Fantasy' AND year >= 2000) OR (genre = 'Horror' AND year >= 1980)", {"genre": "Fantasy", "year": 2010}, T),
+    ("genre IN ('Fantasy', 'Horror', 'Sci-Fi')", {"genre": "Horror"}, T), ("title CONTAINS 'magic'", {"title": "The Magic Kingdom"}, T),
+    ("genre = 'Fantasy' AND year >= 2000", {"genre": "Fantasy", "year": 2010}, T),
+    # :757-795 (edge cases: missing field, null value, empty string)
+    ("genre = 'Fantasy'", {}, F), ("genre = 'Fantasy'", {"genre": None}, F), ("genre = ''", {"genre": ""}, T),
+    # TernaryFilterTests.cs:47-58
+    ("score >= 90 ? status = 'premium' : status = 'basic'", {"score": 95, "status": "premium"}, T),
+    ("score >= 90 ? status = 'premium' : status = 'basic'", {"score": 50, "status": "basic"}, T),
+    ("score >= 90 ? status = 'premium' : status = 'basic'", {"score": 50, "status": "premium"}, F),
+    # FilterVM semantics spelled out in the source (FilterVM.cs:329-358): string vs number coercions
+    ("price > '100'", {"price": 150}, T), ("price > '100'", {"price": "99.5"}, F), ("price > 100", {"price": 100.5}, T),
+    ("year >= '2000'", {"year": "abc"}, T),                      # not numeric -> OrdinalIgnoreCase string compare: "abc" > "2000"
+    ("rating > 7.0", {"rating": 7.0}, F), ("rating > 7.0", {"rating": 7.1}, T), ("rating = 7", {"rating": 7.0}, T), ("rating = '7.0'", {"rating": 7.0}, F),
+    ("NOT status = 'inactive'", {"status": "active"}, T), ("! status = 'inactive'", {"status": "inactive"}, F), ("status != 'inactive'", {"status": "Inactive"}, F),
+    ("name STARTS WITH 'John'", {"name": "john doe"}, T), ("email ENDS WITH '.com'", {"email": "a@b.org"}, F), ("title LIKE '%test%'", {"title": "A Test case"}, T),
+    ("title LIKE 'a_c'", {"title": "ABC"}, T), ("title LIKE 'a_c'", {"title": "abbc"}, F),
+    ("description IS NULL", {}, T), ("description IS NULL", {"description": ""}, T), ("author IS NOT NULL", {"author": "x"}, T),
+    ("a = '1' OR b = '2' AND c = '3'", {"a": "1", "b": "0", "c": "0"}, T), ("(a = '1' OR b = '2') AND c = '3'", {"a": "1", "b": "0", "c": "0"}, F),
+    ("genre = 'Fantasy' && year >= '2000'", {"genre": "Fantasy", "year": 1999}, F), ("author = 'Rowling' | author = 'King'", {"author": "king"}, T),
+    ("score >= 90 ? 'high' : 'low'", {"score": 95}, F),          # a literal branch is not a bool: Execute returns `result is true`
+]
+
+
+@pytest.mark.parametrize("expr,fields,want", VM_KATS)
+def test_vm_kats(expr, fields, want):
+    assert O.filter_eval(expr, fields) is want
+
+
+@pytest.mark.parametrize("expr", ["score >= 90 ? 'high'", "? 'yes' : 'no'", "", "   ", "genre = ", "genre 'x'", "(a = '1'", "a = '1')", "genre IN 'x'", "name STARTS 'J'",
+                                  "a = 'unterminated", "a = '1' AND", "price BETWEEN '1' '2'", "a # '1'"])
+def test_parse_errors(expr):       # FilterParserErrorTests.cs / TernaryFilterTests.cs:243-262
+    with pytest.raises(ValueError):
+        O.filter_eval(expr, {"a": "1"})
+
+
+def test_matches_is_rejected():
+    with pytest.raises(NotImplementedError):
+        O.filter_eval("email MATCHES '^a'", {"email": "a"})
+
+
+def test_double_to_string():
+    for x, s in [(7.5, "7.5"), (8.0, "8"), (0.1, "0.1"), (1e15, "1E+15"), (123456789012345.0, "123456789012345"), (1e-5, "1E-05"), (0.0001, "0.0001"), (-2.25, "-2.25")]:
+        assert O.double_to_string(x) == s, (x, O.double_to_string(x))
+
+
+def test_faceting_kats():
+    """FacetingTests.cs: counts over the result rows of the facetable fields, (count desc, value asc); non-facetable fields absent; the post-filter runs
+    on the returned rows and NumberOfDocumentsInFilter counts the whole collection."""
+    import numpy as np
+    docs = [(1, "The Shawshank Redemption drama"), (2, "The Godfather crime drama"), (3, "The Dark Knight action"), (4, "Pulp Fiction crime"),
+            (5, "Forrest Gump drama"), (6, "Inception action thriller"), (7, "The Matrix action"), (8, "Goodfellas crime drama")]
+    genre = ["Drama", "Crime", "Action", "Crime", "Drama", "Action", "Action", "Crime"]
+    year = np.array([1994, 1972, 2008, 1994, 1994, 2010, 1999, 1990], np.int64)
+    rating = np.array([9.3, 9.2, 9.0, 8.9, 8.8, 8.8, 8.7, 8.7], np.float64)
+    o = O.OracleEngine.create_default(); o.index(docs)
+    o.set_column("genre", genre, facetable=True); o.set_column("year", year, facetable=True); o.set_column("rating", rating, facetable=False)
+    r = o.search_filtered("the", 10, enable_facets=True)
+    assert set(r["keys"]) == {1, 2, 3, 7}
+    assert dict(r["facets"]["genre"]) == {"Action": 2, "Crime": 1, "Drama": 1} and r["facets"]["genre"][0] == ("Action", 2)
+    assert [v for v, _ in r["facets"]["genre"][1:]] == ["Crime", "Drama"]          # equal counts: value ascending
+    assert "rating" not in r["facets"] and dict(r["facets"]["year"]) == {"1994": 1, "1972": 1, "2008": 1, "1999": 1}
+    r = o.search_filtered("the", 10, filter="year >= 1990 AND rating > 8.9", enable_facets=True)
+    assert set(r["keys"]) == {1, 3} and r["in_filter"] == 2                         # docs 1 (1994, 9.3) and 3 (2008, 9.0) of the 8
+    assert dict(r["facets"]["genre"]) == {"Action": 1, "Drama": 1}
+    r = o.search_filtered("drama", 2, filter="genre = 'crime'")
+    assert len(r["keys"]) <= 2 and all(genre[k - 1] == "Crime" for k in r["keys"])   # post-filter of the <= k returned rows (ResultProcessor.cs:56-69)
