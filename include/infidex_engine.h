@@ -112,6 +112,18 @@ int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* doc
                                 int32_t* feat, int64_t cap);
 /* CPUs usable by this process: hardware threads capped by the affinity mask and the cgroup CPU quota (INFX_THREADS overrides);
  * the default size of the host worker pool and of `threads`. */
+/* ---- Query.Filter (Infiscript, Api/FilterParser.cs) and Query.EnableFacets (config 5) -------------------------------------------------
+ * Non-indexed document fields are given as columns (one value per indexed document, in indexing order); the post-filter of the returned
+ * rows (Scoring/ResultProcessor.cs:35-70), Filter.NumberOfDocumentsInFilter and the facet counts (Core/FacetBuilder.cs:19-105) run on the
+ * device (include/infidex_hip.h).  kind: 1 int64, 2 double, 3 UTF-8 strings (arena + n+1 offsets). */
+int32_t infx_engine_add_column(infx_engine* e, const char* name, int32_t kind, int32_t facetable, int64_t n, const int64_t* vals_i, const double* vals_d,
+                               const char* arena, const uint64_t* offs);
+int32_t infx_engine_column_count(infx_engine* e);
+int32_t infx_engine_column_info(infx_engine* e, int32_t col, char* name, int32_t cap, int32_t* facetable, int32_t* num_values);
+int32_t infx_engine_column_value(infx_engine* e, int32_t col, uint32_t code, char* out, int32_t cap);
+int32_t infx_engine_set_filter(infx_session* s, const char* expr_utf8 /* NULL = no filter */, int32_t enable_facets, uint32_t* n_in_filter);
+int32_t infx_engine_facet_column_count(infx_session* s);
+int32_t infx_engine_last_facets(infx_session* s, uint32_t nq, uint32_t qi, uint32_t k, int32_t* col, uint32_t* codes, uint32_t* counts, int32_t cap);
 int32_t infx_engine_effective_cpus(void);
 /* Switches infx_engine_config.want_features at run time (the introspection buffers behind infx_engine_last_stage1 / _last_stage2). */
 int32_t infx_engine_set_introspection(infx_engine* e, int32_t on);

@@ -180,6 +180,39 @@ typedef struct infx_cov_out {
 int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, uint32_t ncand,
                           const infx_cov_cand* cand, infx_cov_out* out, int32_t* feat_out);
 
+/* ---- Infiscript post-filter + facet aggregation on device-resident columns (BASELINE config 5) ---------------------------------------
+ * Replaces ResultProcessor.ApplyFilter (Scoring/ResultProcessor.cs:35-70: FilterVM.Execute per returned row, and over ALL documents for
+ * Filter.NumberOfDocumentsInFilter on first use) and FacetBuilder.BuildFacets (Core/FacetBuilder.cs:19-105) for the rows a search returns.
+ * A column = one non-indexed document field, dictionary-encoded by the host: codes[d] = index of document d's value among the field's
+ * distinct values (GLOBAL internal ids: every shard holds the whole column, 4 B per document).
+ * A filter = a postfix program over LEAVES; leaf l is a bitmap over the codes of column leaf.col (bit v = "the leaf's predicate holds for
+ * distinct value v", evaluated by the host with FilterVM's coercion rules); three-valued evaluation F / T / N as in the reference's
+ * untyped VM: AND(l,r) = l==F ? F : r, OR(l,r) = l==T ? T : r, NOT(x) = x==T ? F : T, TERN(c,a,b) = c==F ? b : a, LIT = N; match iff T. */
+typedef struct infx_filter infx_filter;
+#define INFX_FOP_LEAF 0
+#define INFX_FOP_AND  1
+#define INFX_FOP_OR   2
+#define INFX_FOP_NOT  3
+#define INFX_FOP_TERN 4
+#define INFX_FOP_LIT  5
+#define INFX_FILTER_MAX_OPS 256
+#define INFX_FILTER_MAX_ROWS 64         /* post-filter / facets run on <= 64 returned rows per query (Query.MaxNumberOfRecordsToReturn) */
+#define INFX_MAX_FACET_COLS 8
+typedef struct infx_filter_op { uint32_t op; uint32_t arg; } infx_filter_op;                 /* arg: leaf index for INFX_FOP_LEAF */
+typedef struct infx_filter_leaf { uint32_t col; uint32_t table_off; uint32_t num_values; uint32_t reserved; } infx_filter_leaf;   /* col 0xFFFFFFFF: no such field (null) */
+int32_t infx_upload_column(infx_index* idx, uint32_t col, uint32_t total_docs, const uint32_t* codes, uint32_t num_values);
+int32_t infx_filter_create(infx_index* idx, uint32_t nops, const infx_filter_op* ops, uint32_t nleaves, const infx_filter_leaf* leaves,
+                           uint32_t ntable_words, const uint32_t* tables, infx_filter** out);
+void    infx_filter_destroy(infx_filter* f);
+/* Documents of THIS shard the filter accepts (sum over shards = Filter.NumberOfDocumentsInFilter). */
+int32_t infx_filter_count(infx_stream* s, infx_filter* f, uint32_t* count);
+/* Installs (f != NULL) or clears the post-filter and the facet columns of this stream: every following infx_search_fused /
+ * infx_shard_finalize filters its result rows on the device before they are returned and counts the facet values of the kept rows. */
+int32_t infx_stream_set_postfilter(infx_stream* s, infx_filter* f, uint32_t nfacet, const uint32_t* facet_cols);
+/* Facets of the last search on this stream: for query q and facet column k, n_out[q*nfacet+k] pairs at codes_out / counts_out
+ * [(q*nfacet+k)*INFX_FILTER_MAX_ROWS ..], in row order of first occurrence (the host orders them: count desc, value asc). */
+int32_t infx_last_facets(infx_stream* s, uint32_t nq, uint32_t* codes_out, uint32_t* counts_out, uint32_t* n_out);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------ */
 /* Durations (ms) of the last Stage-1 accumulate / select / Stage-2 launches on this stream, from HIP events recorded on
  * the stream the kernels ran on. */

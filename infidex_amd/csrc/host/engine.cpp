@@ -7,6 +7,8 @@
 //   ResultProcessor.CalculateTruncationIndex src/Infidex/Scoring/ResultProcessor.cs:146-178
 //   TopKHeap / ScoreEntry / ConsolidateSegments  Core/TopKHeap.cs, Core/ScoreEntry.cs:25-36, Scoring/SegmentProcessor.cs:15-37
 #include "query.h"
+#include "filter.h"
+#include <mutex>
 #include "../../../include/infidex_engine.h"
 #include <chrono>
 #include <unordered_map>
@@ -50,6 +52,7 @@ struct Batch {
 };
 
 struct infx_session {
+    std::vector<uint32_t> facetCols;      // engine column indices whose facets the session's stream counts
     infx_engine* e = nullptr;
     Batch* batch = nullptr;
     infx_stream* stream = nullptr;
@@ -61,7 +64,10 @@ struct infx_session {
     std::vector<infx_cov_cand> lastCands; std::vector<infx_cov_out> lastOuts; std::vector<int32_t> lastFeat;
 };
 
+struct CompiledFilter { infx_filter* dev = nullptr; uint32_t inFilter = 0; bool counted = false; };
 struct infx_engine {
+    // non-indexed document fields (DocumentFields) as dictionary-encoded columns + compiled Infiscript filters (config 5)
+    std::vector<filt::Column> columns; std::mutex filterMu; std::unordered_map<std::string, CompiledFilter> filters;
     HostIndex ix;
     infx_engine_config cfg{};
     infx_index* dev = nullptr;
@@ -106,6 +112,7 @@ void infx_engine_destroy(infx_engine* e) {
     if (S && S->stream) infx_stream_destroy(S->stream);
     if (S) delete S->batch;
     delete S;
+    for (auto& kv : e->filters) if (kv.second.dev) infx_filter_destroy(kv.second.dev);
     if (e->dev) infx_destroy(e->dev);
     delete e;
 }
@@ -952,5 +959,103 @@ int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uin
 }
 // raw access for bench.py (HBM-resident inputs are the engine's; these expose the flat host arrays for oracle adoption)
 int32_t infx_engine_device_handles(infx_engine* e, infx_index** idx, infx_stream** st) { if (!e) return INFX_EINVAL; if (idx) *idx = e->dev; if (st) *st = e->def->stream; return INFX_OK; }
+
+
+// ---- Infiscript post-filter + facets (config 5): Query.Filter / Query.EnableFacets (SearchEngine.cs:298-316) ------------------------------
+// One non-indexed document field for all documents (DocumentFields / Field.Value), by internal id: kind 1 int64, 2 double, 3 UTF-8 strings
+// (arena + n+1 offsets).  facetable = Field.Facetable.  After infx_engine_index_documents.
+int32_t infx_engine_add_column(infx_engine* e, const char* name, int32_t kind, int32_t facetable, int64_t n, const int64_t* vi, const double* vd,
+                               const char* arena, const uint64_t* offs) {
+    if (!e || !name || n < 0 || (kind == 1 && !vi) || (kind == 2 && !vd) || (kind == 3 && (!arena || !offs)) || kind < 1 || kind > 3) return efail(INFX_EINVAL, "bad column arguments");
+    if (!e->indexed || n != e->ix.N) return efail(INFX_EINVAL, "a column needs one value per indexed document");
+    if (e->columns.size() >= 64) return efail(INFX_ECAPACITY, "too many columns");
+    for (auto& c : e->columns) if (c.name == name) return efail(INFX_EINVAL, "column exists");
+    filt::Column c; c.name = name; c.facetable = facetable != 0;
+    if (kind == 1) filt::encode_column(c, (size_t)n, [&](size_t d) { filt::Boxed b; b.kind = 1; b.i = vi[d]; return b; }, (long long)0);
+    else if (kind == 2) filt::encode_column(c, (size_t)n, [&](size_t d) { filt::Boxed b; b.kind = 2; b.d = vd[d]; return b; }, (uint64_t)0);
+    else filt::encode_column(c, (size_t)n, [&](size_t d) { filt::Boxed b; b.kind = 3; b.s.assign(arena + offs[d], arena + offs[d + 1]); return b; }, std::string());
+    if (e->dev) {
+        int32_t rc = infx_upload_column(e->dev, (uint32_t)e->columns.size(), (uint32_t)n, c.codes.data(), (uint32_t)c.dict.size());
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+    }
+    e->columns.push_back(std::move(c));
+    return INFX_OK;
+}
+int32_t infx_engine_column_count(infx_engine* e) { return e ? (int32_t)e->columns.size() : 0; }
+int32_t infx_engine_column_info(infx_engine* e, int32_t col, char* name, int32_t cap, int32_t* facetable, int32_t* num_values) {
+    if (!e || col < 0 || col >= (int32_t)e->columns.size()) return INFX_EINVAL;
+    const filt::Column& c = e->columns[col];
+    if (name && cap > 0) snprintf(name, (size_t)cap, "%s", c.name.c_str());
+    if (facetable) *facetable = c.facetable ? 1 : 0; if (num_values) *num_values = (int32_t)c.dict.size();
+    return INFX_OK;
+}
+int32_t infx_engine_column_value(infx_engine* e, int32_t col, uint32_t code, char* out, int32_t cap) {      // ToString() of a distinct value (facet key)
+    if (!e || col < 0 || col >= (int32_t)e->columns.size() || code >= e->columns[col].text.size()) return -1;
+    const std::string& t = e->columns[col].text[code];
+    if (out && cap > 0) snprintf(out, (size_t)cap, "%s", t.c_str());
+    return (int32_t)t.size();
+}
+// Installs Query.Filter (expr, UTF-8; NULL = none) and Query.EnableFacets on the session: every following search on it post-filters its rows
+// on the device and counts the facetable fields.  n_in_filter = Filter.NumberOfDocumentsInFilter (this shard's share when sharded),
+// counted on the device the first time the expression is used.  Status: INFX_EINVAL + message for a syntax error (FilterParseException),
+// INFX_EUNSUPPORTED for MATCHES.
+int32_t infx_engine_set_filter(infx_session* S, const char* expr, int32_t enable_facets, uint32_t* n_in_filter) {
+    if (!S) return efail(INFX_EINVAL, "null session");
+    infx_engine* e = S->e;
+    if (!e->dev || !S->stream) return efail(INFX_EHIP, "no GPU: the post-filter runs on the device");
+    infx_filter* dev = nullptr; uint32_t cnt = 0;
+    if (expr) {
+        std::lock_guard<std::mutex> lk(e->filterMu);
+        auto it = e->filters.find(expr);
+        if (it == e->filters.end()) {
+            filt::Program P;
+            try { P = filt::parse(expr); }
+            catch (const filt::Unsupported& x) { return efail(INFX_EUNSUPPORTED, x.what()); }
+            catch (const filt::SyntaxError& x) { return efail(INFX_EINVAL, std::string("filter syntax error: ") + x.what()); }
+            std::vector<infx_filter_op> ops; std::vector<infx_filter_leaf> leaves; std::vector<uint32_t> tables, w;
+            for (auto& in : P.code) ops.push_back(infx_filter_op{in.op, in.arg});
+            for (auto& L : P.leaves) {
+                int ci = -1; for (size_t c = 0; c < e->columns.size(); c++) if (e->columns[c].name == L.field) ci = (int)c;      // field names are case sensitive (Dictionary<string, Field>)
+                filt::leaf_table(L, ci >= 0 ? &e->columns[ci] : nullptr, w);
+                leaves.push_back(infx_filter_leaf{ci >= 0 ? (uint32_t)ci : 0xFFFFFFFFu, (uint32_t)tables.size(), ci >= 0 ? (uint32_t)e->columns[ci].dict.size() : 1u, 0});
+                tables.insert(tables.end(), w.begin(), w.end());
+            }
+            CompiledFilter cf;
+            int32_t rc = infx_filter_create(e->dev, (uint32_t)ops.size(), ops.data(), (uint32_t)leaves.size(), leaves.data(), (uint32_t)tables.size(), tables.data(), &cf.dev);
+            if (rc) { g_eerr = infx_last_error(); return rc; }
+            it = e->filters.emplace(expr, cf).first;
+        }
+        if (!it->second.counted) {       // ResultProcessor.cs:39-54: first use runs the filter over every document
+            int32_t rc = infx_filter_count(S->stream, it->second.dev, &it->second.inFilter);
+            if (rc) { g_eerr = infx_last_error(); return rc; }
+            it->second.counted = true;
+        }
+        dev = it->second.dev; cnt = it->second.inFilter;
+    }
+    S->facetCols.clear();
+    if (enable_facets) for (size_t c = 0; c < e->columns.size() && S->facetCols.size() < INFX_MAX_FACET_COLS; c++) if (e->columns[c].facetable) S->facetCols.push_back((uint32_t)c);
+    int32_t rc = infx_stream_set_postfilter(S->stream, dev, (uint32_t)S->facetCols.size(), S->facetCols.data());
+    if (rc) { g_eerr = infx_last_error(); return rc; }
+    if (n_in_filter) *n_in_filter = cnt;
+    return INFX_OK;
+}
+// Facets of query qi of the session's last search: for the k-th facetable column (engine column index in *col), up to cap (code, count) pairs ordered
+// as FacetBuilder does (count descending, value ascending), at most 100.  Returns the number of pairs, -1 on error.
+int32_t infx_engine_last_facets(infx_session* S, uint32_t nq, uint32_t qi, uint32_t k, int32_t* col, uint32_t* codes, uint32_t* counts, int32_t cap) {
+    if (!S || !S->stream || qi >= nq || k >= S->facetCols.size()) return -1;
+    const uint32_t nf = (uint32_t)S->facetCols.size();
+    std::vector<uint32_t> cd((size_t)nq * nf * INFX_FILTER_MAX_ROWS), ct(cd.size()), nn((size_t)nq * nf);
+    if (infx_last_facets(S->stream, nq, cd.data(), ct.data(), nn.data())) { g_eerr = infx_last_error(); return -1; }
+    const filt::Column& C = S->e->columns[S->facetCols[k]];
+    const size_t o = ((size_t)qi * nf + k) * INFX_FILTER_MAX_ROWS; const uint32_t n = nn[(size_t)qi * nf + k];
+    std::vector<std::pair<uint32_t, uint32_t>> v;
+    for (uint32_t i = 0; i < n; i++) if (cd[o + i] < C.text.size() && !C.text[cd[o + i]].empty()) v.push_back({cd[o + i], ct[o + i]});     // empty strings are not facet values (:95-99)
+    std::sort(v.begin(), v.end(), [&](auto& a, auto& b) { if (a.second != b.second) return a.second > b.second; return C.rank[a.first] < C.rank[b.first]; });
+    if (v.size() > 100) v.resize(100);
+    if (col) *col = (int32_t)S->facetCols[k];
+    int32_t m = 0; for (auto& x : v) { if (m >= cap) break; codes[m] = x.first; counts[m] = x.second; m++; }
+    return m;
+}
+int32_t infx_engine_facet_column_count(infx_session* S) { return S ? (int32_t)S->facetCols.size() : 0; }
 
 } // extern "C"

@@ -27,6 +27,7 @@
 #include "../../include/infidex_hip.h"
 
 #define WAVE 64
+#define FILT_MAXCOL 64
 
 static thread_local std::string g_err;
 static int32_t fail(int32_t code, const char* fmt, const char* a = "") {
@@ -65,6 +66,7 @@ struct infx_index {
     std::vector<uint64_t> hPostLen;   // true list lengths
     std::vector<int32_t> hDf;
     std::vector<uint32_t> hSkipIdx;   // host copy of DevIndex::skipIdx (filled by infx_upload_postings)
+    const uint32_t* colCodes[FILT_MAXCOL] = {}; uint32_t colValues[FILT_MAXCOL] = {}; uint32_t colDocs[FILT_MAXCOL] = {};   // device-resident columns (infx_upload_column)
     std::vector<uint64_t> hPsOff;
     int rank = 0, nranks = 1;
 };
@@ -205,10 +207,20 @@ __host__ __device__ static inline SelRule make_rule(const infx_query& Q, const u
 }
 
 #include "fused.hip.inc"
+#include "filter.hip.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
+struct infx_filter {
+    infx_index* ix; DevFilter d{}; uint32_t nops = 0, nleaves = 0; void *dOps = nullptr, *dLeaves = nullptr, *dTables = nullptr;
+};
+
 struct infx_stream {
     infx_index* ix;
+    // post-filter / facets (infx_stream_set_postfilter): applied to the rows of every fused / sharded finalize on this stream
+    infx_filter* postFilter = nullptr; uint32_t nFacet = 0; uint32_t facetCols[INFX_MAX_FACET_COLS] = {};
+    void *dFDocs = nullptr, *dFacetCols = nullptr, *dFacCodes = nullptr, *dFacCounts = nullptr, *dFacN = nullptr;
+    size_t capFDocs = 0, capFacCodes = 0, capFacCounts = 0, capFacN = 0;
+    std::vector<uint32_t> hFacCodes, hFacCounts, hFacN; uint32_t facetNq = 0;
     hipStream_t st = nullptr;
     hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1, evSync;
     // fused pipeline workspaces
@@ -601,7 +613,7 @@ void infx_stream_destroy(infx_stream* s) {
     hipSetDevice(s->ix->cfg.device);
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
-                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters};
+                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters};
     for (void* p : ps) if (p) hipFree(p);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
@@ -953,11 +965,30 @@ static int32_t fused_enqueue_finalize(infx_stream* s, uint32_t nq, int32_t depth
     HIPCHK(hipMemsetAsync(s->dFErr, 0, 4, s->st));
     HIPCHK(hipEventRecord(s->evF0, s->st));
     const size_t lds = (size_t)Cp * (8 + 4 + 4 + 2 + 1 + 1) + (P2_THREADS + 1) * 4 + 64;
+    const bool post = s->postFilter != nullptr || s->nFacet > 0;
+    if (post && max_results > INFX_FILTER_MAX_ROWS) return fail(INFX_EUNSUPPORTED, "post-filter / facets run on at most INFX_FILTER_MAX_ROWS returned rows per query%s");
+    if (post) GROW(s->dFDocs, s->capFDocs, (size_t)nq * max_results * 4);
     k_finalize<<<nq, P2_THREADS, lds, s->st>>>(ix->d, (const infx_fused_query*)s->dFQ, (const FusedMeta*)s->dFMeta, (const infx_cov_cand*)s->dCovC,
                                                 (const infx_cov_out*)s->dCovO, (const infx_hit*)s->dFS1, depth, (int)Cp, max_results,
                                                 (long long*)s->dFKeys, (float*)s->dFScores, ties ? (uint8_t*)s->dFTies : nullptr,
-                                                (uint32_t*)s->dFCounts, (uint32_t*)s->dFFlags, (uint32_t*)s->dFErr);
+                                                (uint32_t*)s->dFCounts, (uint32_t*)s->dFFlags, (uint32_t*)s->dFErr, post ? (int32_t*)s->dFDocs : nullptr);
     HIPCHK(hipGetLastError());
+    s->facetNq = 0;
+    if (post) {     // ResultProcessor.ApplyFilter + FacetBuilder on the rows just produced, before they leave the device
+        const size_t fe = (size_t)nq * std::max<uint32_t>(1, s->nFacet) * INFX_FILTER_MAX_ROWS;
+        GROW(s->dFacCodes, s->capFacCodes, fe * 4); GROW(s->dFacCounts, s->capFacCounts, fe * 4); GROW(s->dFacN, s->capFacN, (size_t)nq * std::max<uint32_t>(1, s->nFacet) * 4);
+        if (!s->dFacetCols) HIPCHK(hipMalloc(&s->dFacetCols, INFX_MAX_FACET_COLS * 4));
+        UP(s->dFacetCols, s->facetCols, INFX_MAX_FACET_COLS * 4);
+        DevColumns cols; for (int c = 0; c < FILT_MAXCOL; c++) cols.codes[c] = ix->colCodes[c];
+        k_postfilter<<<nq, WAVE, 0, s->st>>>(s->postFilter ? s->postFilter->d : DevFilter{}, s->postFilter ? 1 : 0, cols, max_results, (long long*)s->dFKeys, (float*)s->dFScores,
+                                            ties ? (uint8_t*)s->dFTies : nullptr, (int32_t*)s->dFDocs, (uint32_t*)s->dFCounts, (int)s->nFacet, (const uint32_t*)s->dFacetCols,
+                                            (uint32_t*)s->dFacCodes, (uint32_t*)s->dFacCounts, (uint32_t*)s->dFacN);
+        HIPCHK(hipGetLastError());
+        if (s->nFacet) {
+            s->hFacCodes.resize(fe); s->hFacCounts.resize(fe); s->hFacN.resize((size_t)nq * s->nFacet); s->facetNq = nq;
+            DOWN(s->hFacCodes.data(), s->dFacCodes, fe * 4); DOWN(s->hFacCounts.data(), s->dFacCounts, fe * 4); DOWN(s->hFacN.data(), s->dFacN, (size_t)nq * s->nFacet * 4);
+        }
+    }
     HIPCHK(hipEventRecord(s->evF1, s->st));
     s->timedFused = true;
     return INFX_OK;
@@ -1186,6 +1217,86 @@ int32_t infx_last_candidates(infx_stream* s, uint64_t* n) {
 int32_t infx_last_alg_bytes(infx_stream* s, uint64_t* bytes) {
     if (!s || !bytes) return fail(INFX_EINVAL, "null argument%s");
     *bytes = s->lastAlgBytes; return INFX_OK;
+}
+
+
+// ---- Infiscript post-filter + facets (config 5) --------------------------------------------------------------------------------------
+int32_t infx_upload_column(infx_index* ix, uint32_t col, uint32_t total_docs, const uint32_t* codes, uint32_t num_values) {
+    if (!ix || col >= FILT_MAXCOL || (total_docs && !codes)) return fail(INFX_EINVAL, "bad column arguments%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    uint32_t* d = nullptr;
+    HIPCHK(dalloc(ix, &d, (size_t)total_docs + 1));
+    if (total_docs) HIPCHK(hipMemcpy(d, codes, (size_t)total_docs * 4, hipMemcpyHostToDevice));
+    ix->colCodes[col] = d; ix->colValues[col] = num_values; ix->colDocs[col] = total_docs;
+    return INFX_OK;
+}
+int32_t infx_filter_create(infx_index* ix, uint32_t nops, const infx_filter_op* ops, uint32_t nleaves, const infx_filter_leaf* leaves,
+                           uint32_t ntable_words, const uint32_t* tables, infx_filter** out) {
+    if (!ix || !out || !nops || !ops || (nleaves && (!leaves || !tables))) return fail(INFX_EINVAL, "null argument%s");
+    if (nops > INFX_FILTER_MAX_OPS) return fail(INFX_ECAPACITY, "filter program too long%s");
+    int depth = 0, maxDepth = 0;
+    for (uint32_t i = 0; i < nops; i++) {          // the program must be a well-formed postfix expression whose stack fits the kernels' 32 slots
+        const uint32_t o = ops[i].op;
+        if (o == INFX_FOP_LEAF) { if (ops[i].arg >= nleaves) return fail(INFX_EINVAL, "filter leaf index out of range%s"); depth++; }
+        else if (o == INFX_FOP_LIT) depth++;
+        else if (o == INFX_FOP_NOT) { if (depth < 1) return fail(INFX_EINVAL, "malformed filter program%s"); }
+        else if (o == INFX_FOP_AND || o == INFX_FOP_OR) { if (depth < 2) return fail(INFX_EINVAL, "malformed filter program%s"); depth--; }
+        else if (o == INFX_FOP_TERN) { if (depth < 3) return fail(INFX_EINVAL, "malformed filter program%s"); depth -= 2; }
+        else return fail(INFX_EINVAL, "unknown filter opcode%s");
+        maxDepth = std::max(maxDepth, depth);
+    }
+    if (depth != 1 || maxDepth > 32) return fail(INFX_EINVAL, "malformed or too deeply nested filter program%s");
+    for (uint32_t l = 0; l < nleaves; l++) {
+        const infx_filter_leaf& L = leaves[l];
+        if (L.col != 0xFFFFFFFFu && (L.col >= FILT_MAXCOL || !ix->colCodes[L.col])) return fail(INFX_EINVAL, "filter refers to a column that was not uploaded%s");
+        if ((uint64_t)L.table_off + (L.num_values + 31) / 32 > ntable_words) return fail(INFX_EINVAL, "filter leaf table out of range%s");
+    }
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    infx_filter* f = new infx_filter(); f->ix = ix; f->nops = nops; f->nleaves = nleaves;
+    auto bail = [&](int32_t rc) { infx_filter_destroy(f); return rc; };
+    if (hipMalloc(&f->dOps, nops * sizeof(infx_filter_op)) != hipSuccess || hipMalloc(&f->dLeaves, std::max<size_t>(1, nleaves) * sizeof(infx_filter_leaf)) != hipSuccess ||
+        hipMalloc(&f->dTables, std::max<size_t>(1, ntable_words) * 4) != hipSuccess) return bail(fail(INFX_ENOMEM, "filter allocation failed%s"));
+    if (hipMemcpy(f->dOps, ops, nops * sizeof(infx_filter_op), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(INFX_EHIP, "filter upload failed%s"));
+    if (nleaves && (hipMemcpy(f->dLeaves, leaves, nleaves * sizeof(infx_filter_leaf), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(f->dTables, tables, (size_t)ntable_words * 4, hipMemcpyHostToDevice) != hipSuccess)) return bail(fail(INFX_EHIP, "filter upload failed%s"));
+    f->d = DevFilter{(const infx_filter_op*)f->dOps, nops, (const infx_filter_leaf*)f->dLeaves, nleaves, (const uint32_t*)f->dTables};
+    *out = f; return INFX_OK;
+}
+void infx_filter_destroy(infx_filter* f) {
+    if (!f) return;
+    hipSetDevice(f->ix->cfg.device);
+    if (f->dOps) hipFree(f->dOps); if (f->dLeaves) hipFree(f->dLeaves); if (f->dTables) hipFree(f->dTables);
+    delete f;
+}
+int32_t infx_filter_count(infx_stream* s, infx_filter* f, uint32_t* count) {
+    if (!s || !f || !count || f->ix != s->ix) return fail(INFX_EINVAL, "bad filter arguments%s");
+    infx_index* ix = s->ix;
+    if (!ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    for (uint32_t l = 0; l < f->nleaves; l++) { /* columns are indexed by GLOBAL internal id: they must cover this shard */ }
+    HIPCHK(hipMemsetAsync(s->dExactStat, 0, 4, s->st));
+    DevColumns cols; for (int c = 0; c < FILT_MAXCOL; c++) cols.codes[c] = ix->colCodes[c];
+    const int n = ix->d.N;
+    if (n > 0) k_filter_count<<<std::min(4096, (n + 255) / 256), 256, 0, s->st>>>(f->d, cols, ix->d.docBase, n, s->dExactStat);
+    HIPCHK(hipGetLastError());
+    DOWN(count, s->dExactStat, 4);
+    SYNC();
+    return INFX_OK;
+}
+int32_t infx_stream_set_postfilter(infx_stream* s, infx_filter* f, uint32_t nfacet, const uint32_t* facet_cols) {
+    if (!s || nfacet > INFX_MAX_FACET_COLS || (nfacet && !facet_cols) || (f && f->ix != s->ix)) return fail(INFX_EINVAL, "bad post-filter arguments%s");
+    for (uint32_t c = 0; c < nfacet; c++) if (facet_cols[c] >= FILT_MAXCOL || !s->ix->colCodes[facet_cols[c]]) return fail(INFX_EINVAL, "facet column was not uploaded%s");
+    s->postFilter = f; s->nFacet = nfacet;
+    for (uint32_t c = 0; c < INFX_MAX_FACET_COLS; c++) s->facetCols[c] = c < nfacet ? facet_cols[c] : 0;
+    return INFX_OK;
+}
+int32_t infx_last_facets(infx_stream* s, uint32_t nq, uint32_t* codes_out, uint32_t* counts_out, uint32_t* n_out) {
+    if (!s || !codes_out || !counts_out || !n_out) return fail(INFX_EINVAL, "null argument%s");
+    if (nq != s->facetNq || !s->nFacet) return fail(INFX_EINVAL, "no facets of a batch of this size on the stream%s");
+    std::memcpy(codes_out, s->hFacCodes.data(), s->hFacCodes.size() * 4); std::memcpy(counts_out, s->hFacCounts.data(), s->hFacCounts.size() * 4);
+    std::memcpy(n_out, s->hFacN.data(), s->hFacN.size() * 4);
+    return INFX_OK;
 }
 
 } // extern "C"

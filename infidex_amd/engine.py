@@ -49,6 +49,8 @@ class Query:       # Api/Query.cs:9-40
     max_number_of_records_to_return: int = 10
     coverage_depth: int = 500
     enable_coverage: bool = True
+    filter: Optional[str] = None           # Infiscript expression (Filter.Parse), applied to the returned rows (ResultProcessor.ApplyFilter)
+    enable_facets: bool = False
 
 
 @dataclass
@@ -64,6 +66,8 @@ class Result:      # Api/Result.cs
     unsupported: bool = False
     used_coverage: bool = False
     stage1_fallback: bool = False
+    facets: Optional[dict] = None          # field -> [(value, count)] (count desc, value asc), Api/Result.cs Facets
+    total_in_filter: int = 0               # Filter.NumberOfDocumentsInFilter
 
 
 class _Cfg(C.Structure):
@@ -168,9 +172,63 @@ class SearchEngine:
                                                        _p(offs, C.c_uint64), len(fw), _p(fw, C.c_int32)))
         self._keep = None
 
+    # ---- non-indexed document fields (DocumentFields) as columns: filterable / facetable (config 5) ----
+    def set_column(self, name, values, facetable=False):
+        """One value per indexed document, in indexing order: int64 / float64 numpy array or a sequence of str."""
+        n = len(values)
+        if isinstance(values, np.ndarray) and values.dtype.kind in "iu":
+            v = np.ascontiguousarray(values, np.int64)
+            self._check(self.L.infx_engine_add_column(self.h, name.encode(), 1, int(facetable), C.c_int64(n), _p(v, C.c_int64), None, None, None))
+        elif isinstance(values, np.ndarray) and values.dtype.kind == "f":
+            v = np.ascontiguousarray(values, np.float64)
+            self._check(self.L.infx_engine_add_column(self.h, name.encode(), 2, int(facetable), C.c_int64(n), None, _p(v, C.c_double), None, None))
+        else:
+            bs = [str(x).encode() for x in values]
+            offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum([len(b) for b in bs])
+            arena = b"".join(bs) + b"\0"
+            self._check(self.L.infx_engine_add_column(self.h, name.encode(), 3, int(facetable), C.c_int64(n), None, None, C.c_char_p(arena), _p(offs, C.c_uint64)))
+
+    def _default_session(self):
+        h = C.c_void_p(); self._check(self.L.infx_engine_default_session(self.h, C.byref(h))); return h
+
+    def search_filtered(self, texts: Sequence[str], max_results=10, depth=500, enable_coverage=True, filter=None, enable_facets=False, session=None):
+        """Search(Query) with Query.Filter / Query.EnableFacets for a batch sharing one filter: post-filter and facet counts run on the device."""
+        sh = session.h if session is not None else self._default_session()
+        nin = C.c_uint32(0)
+        self._check(self.L.infx_engine_set_filter(sh, filter.encode() if filter is not None else None, int(enable_facets), C.byref(nin)))
+        try:
+            arena, offs = pack_texts(texts)
+            keys, scores, ties, counts, flags = (session or self).search_packed(arena, offs, max_results, depth, enable_coverage)
+            nq = len(texts)
+            nf = self.L.infx_engine_facet_column_count(sh) if enable_facets else 0
+            out = []
+            for i in range(nq):
+                recs = [ScoreEntry(float(scores[i, k]), int(keys[i, k]), int(ties[i, k])) for k in range(int(counts[i]))]
+                facets = None
+                if enable_facets:
+                    facets = {}
+                    for k in range(nf):
+                        col = C.c_int32(0); codes = np.zeros(128, np.uint32); cnts = np.zeros(128, np.uint32)
+                        m = self.L.infx_engine_last_facets(sh, nq, i, k, C.byref(col), _p(codes, C.c_uint32), _p(cnts, C.c_uint32), 128)
+                        if m < 0:
+                            self._check(1)
+                        if m > 0:
+                            nb = C.create_string_buffer(256); self.L.infx_engine_column_info(self.h, col.value, nb, 256, None, None)
+                            vals = []
+                            for j in range(m):
+                                vb = C.create_string_buffer(1024); self.L.infx_engine_column_value(self.h, col.value, int(codes[j]), vb, 1024)
+                                vals.append((vb.value.decode(), int(cnts[j])))
+                            facets[nb.value.decode()] = vals
+                out.append(Result(recs, bool(flags[i] & 1), bool(flags[i] & 2), bool(flags[i] & 4), facets, int(nin.value)))
+            return out
+        finally:
+            self.L.infx_engine_set_filter(sh, None, 0, None)
+
     # ---- search ----
     def search(self, query: Union[Query, str], max_results: Optional[int] = None) -> Result:
         q = query if isinstance(query, Query) else Query(query, max_results or 10)
+        if q.filter is not None or q.enable_facets:
+            return self.search_filtered([q.text], q.max_number_of_records_to_return, q.coverage_depth, q.enable_coverage, q.filter, q.enable_facets)[0]
         return self.search_batch([q.text], q.max_number_of_records_to_return, q.coverage_depth, q.enable_coverage)[0]
 
     def search_batch_raw(self, texts: Sequence[str], max_results=10, depth=500, enable_coverage=True):

@@ -1,0 +1,73 @@
+"""Config 5 on the GPU: Infiscript post-filter + NumberOfDocumentsInFilter + facet aggregation on device-resident columns, against the oracle
+(oracle/filter.hpp, pinned by the reference's BytecodeVM / FilterParser / Ternary / Faceting tests in tests/test_oracle_filter_kats.py)."""
+import numpy as np
+import pytest
+
+from infidex_amd import SearchEngine, Document, Query
+from infidex_amd.engine import InfidexError
+from tests import oracle_lib as O
+from tests.test_oracle_filter_kats import VM_KATS
+from tools.synth import Synth
+
+pytestmark = pytest.mark.gpu
+GENRES = ["Action", "Comedy", "Drama", "Horror", "Sci-Fi", "Romance", "Thriller", "Western", "Fantasy", "Mystery", "Crime", "Animation"]
+
+
+def columns(n, seed=5):
+    rng = np.random.default_rng(seed)
+    year = rng.integers(1950, 2025, n).astype(np.int64)
+    rating = np.round(rng.uniform(1.0, 10.0, n), 1)
+    genre = [GENRES[i] for i in rng.integers(0, len(GENRES), n)]
+    return year, rating, genre
+
+
+@pytest.fixture(scope="module")
+def pair():
+    s = Synth(2, docs=40000)
+    arena, offs = s.docs()
+    e = SearchEngine.create_default(device=0); e.index_flat(None, arena, offs, s.field_weights)
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    year, rating, genre = columns(40000)
+    for x in (e, o):
+        x.set_column("year", year, facetable=True); x.set_column("rating", rating, facetable=False); x.set_column("genre", genre, facetable=True)
+    qa, qo = s.queries(120, qseed=31, fuzz=0.3)
+    return e, o, Synth.texts(qa, qo), (year, rating, genre)
+
+
+@pytest.mark.parametrize("flt", ["year >= 2000 AND rating > 7.0", "genre IN ('Drama', 'crime') OR year < 1960", "NOT (rating <= 5) AND genre != 'Horror'",
+                                 "year BETWEEN 1990 AND 1999", "genre STARTS WITH 'S' OR genre LIKE '%er'", "rating >= 9.5 ? genre = 'Action' : year >= 2020",
+                                 "rating = 7", "rating = '7.0'", "nosuchfield IS NULL AND year > 2010", None])
+def test_filter_and_facets_match_the_oracle(pair, flt):
+    e, o, texts, cols = pair
+    res = e.search_filtered(texts, 20, filter=flt, enable_facets=True)
+    for q, r in zip(texts, res):
+        w = o.search_filtered(q, 20, filter=flt, enable_facets=True)
+        assert [x.document_id for x in r.records] == w["keys"], (flt, q)
+        assert r.total_in_filter == w["in_filter"], (flt, r.total_in_filter, w["in_filter"])
+        assert (r.facets or {}) == w["facets"], (flt, q, r.facets, w["facets"])
+
+
+def test_vm_known_answers_through_the_device():
+    """Every VM known answer of the reference (restated in test_oracle_filter_kats.VM_KATS) evaluated by the product: one document whose fields are
+    the KAT's, the expression as the post-filter of a query that returns it."""
+    for expr, fields, want in VM_KATS:
+        e = SearchEngine.create_default(device=0); e.index_documents([Document(1, "alpha bravo"), Document(2, "charlie delta")])
+        for name, v in fields.items():
+            if v is None:
+                continue                                    # a null field = no column value: the engine treats an absent column as null
+            if isinstance(v, float): e.set_column(name, np.array([v, v], np.float64))
+            elif isinstance(v, int): e.set_column(name, np.array([v, v], np.int64))
+            else: e.set_column(name, [v, v])
+        r = e.search(Query("alpha bravo", 10, filter=expr))
+        assert ([x.document_id for x in r.records] == [1]) is want, (expr, fields, r.records)
+        assert r.total_in_filter == (2 if want else 0), (expr, r.total_in_filter)
+
+
+def test_syntax_errors_and_unsupported():
+    e = SearchEngine.create_default(device=0); e.index_documents([Document(1, "alpha bravo")]); e.set_column("a", ["1"])
+    for bad in ["score >= 90 ? 'high'", "genre = ", "(a = '1'", "a # '1'", ""]:
+        with pytest.raises(InfidexError):
+            e.search(Query("alpha", 10, filter=bad))
+    with pytest.raises(InfidexError):
+        e.search(Query("alpha", 10, filter="a MATCHES '^1'"))
+    assert [x.document_id for x in e.search(Query("alpha", 10, filter="a = '1'")).records] == [1]      # the session recovers after an error
