@@ -110,6 +110,12 @@ def main():
     else:
         eng = SearchEngine.create_default(device=local_rank, threads=bthreads, range_docs=args.range_docs)
     eng.index_flat(None, arena, offs, syn.field_weights)
+    flt = syn.cfg.get("filter")                       # config 5: Query.Filter + Query.EnableFacets on device-resident columns
+    cols5 = None
+    if flt:
+        from tools.synth import config5_columns
+        cols5 = config5_columns(args.docs)
+        eng.set_column("year", cols5[0], facetable=True); eng.set_column("rating", cols5[1], facetable=False); eng.set_column("genre", cols5[2], facetable=True)
     t_index = time.time() - t0
 
     nsteps = args.warmup + args.steps
@@ -154,6 +160,9 @@ def main():
     else:
         nsess = max(1, min(args.sessions, args.steps))
         sessions = [Session(eng) for _ in range(nsess)]
+        in_filter = None
+        if flt:
+            tf0 = time.time(); in_filter = [se.set_filter(flt, True) for se in sessions][0]; t_filter_first_use = time.time() - tf0
         for s in range(args.warmup):
             sessions[s % nsess].search_packed(batches[s][0], batches[s][1], k, 500)
         sync()
@@ -254,6 +263,9 @@ def main():
                      "note": "achieved = SURVEY 8(d) algorithmic bytes / k_accumulate duration (HIP events on the launch stream, uncontended launch)"},
         "setup_s": {"corpus_gen": t_gen, "index_build_and_upload": t_index, "host_threads": bthreads},
     }
+    if flt and not sharded:
+        out["config"]["filter"] = flt; out["config"]["facets"] = ["year", "genre"]
+        out["filter"] = {"documents_in_filter": in_filter, "first_use_s_incl_compile_and_device_count": t_filter_first_use}
     # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read from inside the process).  The
     # committed measurement is attached only if it was taken on THIS build of the kernel (sha256 of csrc/stage1.hip.inc) and this workload.
     try:
@@ -289,10 +301,18 @@ def main():
         secs1, _, lat1 = o.timed_batch(texts[:min(sample, 24)], k, 500, threads=1, want_latency=True)
         # identical top-k DocumentId sets on the sample (parity is asserted in tests/; reported here)
         gk, gc = first_keys
+        if flt:        # config 5: the rows are post-filtered; compare against the oracle's filtered search (sequential, smaller sample) incl. facets
+            o.set_column("year", cols5[0], facetable=True); o.set_column("rating", cols5[1], facetable=False); o.set_column("genre", cols5[2], facetable=True)
+            sample = min(sample, 96)
+            want = [o.search_filtered(texts[i], k, 500, filter=flt, enable_facets=True) for i in range(sample)]
+            okeys = [np.asarray(w["keys"], np.int64) for w in want]
+            got = eng.search_filtered(texts[:sample], k, 500, filter=flt, enable_facets=True)
+            out["filter"]["facets_identical"] = f"{sum(1 for g, w in zip(got, want) if (g.facets or {}) == w['facets'])}/{sample}"
+            out["filter"]["documents_in_filter_oracle"] = want[0]["in_filter"] if want else None
         differ = [i for i in range(sample) if set(gk[i, :gc[i]].tolist()) != set(x for x in okeys[i].tolist() if x >= 0)]
         same = sample - len(differ)
         from tests.parity_classify import classify
-        cls = classify(eng, o, [texts[i] for i in differ], k) if differ else []
+        cls = classify(eng, o, [texts[i] for i in differ], k) if (differ and not flt) else []
         out["cpu_baseline"] = {"value": sample / secs, "unit": "queries/s", "cores": cthreads, "kind": "port",
                                "sample": f"first {sample} queries of the first timed batch, same 10M index semantics, one in-flight query per thread; "
                                          f"oracle = C++ restatement of the reference algorithm (not the .NET binary)",

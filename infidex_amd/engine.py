@@ -364,6 +364,12 @@ class Session:
                                                                    _p(ties, C.c_uint8), _p(counts, C.c_uint32), _p(flags, C.c_uint32)))
         return keys, scores, ties, counts, flags
 
+    def set_filter(self, expr=None, enable_facets=False):
+        """Installs Query.Filter / Query.EnableFacets on this session (None clears); returns Filter.NumberOfDocumentsInFilter."""
+        nin = C.c_uint32(0)
+        self.engine._check(self.L.infx_engine_set_filter(self.h, expr.encode() if expr is not None else None, int(enable_facets), C.byref(nin)))
+        return int(nin.value)
+
     def last_timings(self):
         host = np.zeros(5, np.float64); kern = np.zeros(5, np.float32); alg = np.zeros(6, np.uint64)
         self.engine._check(self.L.infx_engine_session_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))

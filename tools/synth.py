@@ -14,7 +14,17 @@ CONFIGS = {
     2: dict(docs=100_000, vocab=50_000, fields=[(4, 12, 1)], qwords=(2, 2), fuzz=0.0, need_field=-1, k=10),
     3: dict(docs=1_000_000, vocab=200_000, fields=[(2, 6, 0), (8, 24, 2)], qwords=(3, 3), fuzz=1.0, need_field=0, k=20),
     4: dict(docs=10_000_000, vocab=1_000_000, fields=[(4, 12, 1)], qwords=(2, 3), fuzz=0.3, need_field=-1, k=20),
+    # config 5 = config 4 + non-indexed fields year / rating / genre, Filter.Parse("year >= 2000 AND rating > 7.0"), EnableFacets
+    5: dict(docs=10_000_000, vocab=1_000_000, fields=[(4, 12, 1)], qwords=(2, 3), fuzz=0.3, need_field=-1, k=20, filter="year >= 2000 AND rating > 7.0"),
 }
+GENRES = ["Action", "Comedy", "Drama", "Horror", "Sci-Fi", "Romance", "Thriller", "Western", "Fantasy", "Mystery", "Crime", "Animation"]
+
+
+def config5_columns(n, seed=0x1F1DE5 + 5):
+    """year in U[1950, 2024] (int), rating in U[1.0, 10.0] (1 decimal), genre in 12 values; year and genre facetable."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    return rng.integers(1950, 2025, n).astype(np.int64), np.round(rng.uniform(1.0, 10.0, n), 1), [GENRES[i] for i in rng.integers(0, len(GENRES), n)]
 
 
 def build():
