@@ -83,7 +83,8 @@ int32_t infx_session_phase3(infx_session* s, int32_t nranks, const infx_hit* all
 int32_t infx_session_outs(infx_session* s, int32_t* outs3);
 /* the same phases with caller-owned exchange buffers on the host OR the device (nd x depth hits + nd counts; nshards x ... ; nq x 2*depth
  * rows of 3 int32): with device tensors the collectives (RCCL) work in place and nothing crosses PCIe. infx_session_phase4 accepts either. */
-int32_t infx_session_phase2x(infx_session* s, const uint32_t* global_counts, void* hits, void* hitcounts);
+int32_t infx_session_phase1x(infx_session* s, const uint32_t* global_union_counts, void* counts /* nq x INFX_NCLASS, host or device */, uint32_t* ndev);
+int32_t infx_session_phase2x(infx_session* s, const uint32_t* global_counts /* host or device */, void* hits, void* hitcounts);
 int32_t infx_session_phase3x(infx_session* s, int32_t nranks, const void* all_hits, const void* all_hitcounts, int32_t max_results, int32_t enable_coverage, void* outs);
 int32_t infx_session_phase4(infx_session* s, const int32_t* merged_outs3, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                             uint32_t* out_counts, uint32_t* out_flags);

@@ -126,7 +126,7 @@ typedef struct infx_counts { uint32_t c[INFX_NCLASS]; } infx_counts;
 
 /* Stage 1a: stream postings, accumulate BM25+ in LDS, emit candidate supersets + class counts (device resident). */
 int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
-                               uint32_t extra_n, const int32_t* extra_docs, infx_counts* counts_out /* nq, host */);
+                               uint32_t extra_n, const int32_t* extra_docs, infx_counts* counts_out /* nq; host memory or a device buffer */);
 /* Stage 1b: apply the tier rules with (global) counts, select the top-`depth` per query ordered by
  * (score desc, DocumentKey asc). out: nq*depth hits; out_count: nq. Replaces UpdateTopK/PriorityQueue (Bm25Scorer.cs:654-670). */
 int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* counts /* nq, host, global */,

@@ -732,6 +732,21 @@ int32_t infx_session_phase1(infx_session* S, const uint32_t* global_union_counts
     if (ndev) *ndev = S->batch->nd;
     return INFX_OK;
 }
+// phase 1 with the class histograms written straight into caller memory on the host OR the device (nq x INFX_NCLASS uint32, the first ndev rows
+// are used): with a device tensor the count all-reduce (Exchange 1) runs in place on it and infx_session_phase2x reads it back from HBM.
+int32_t infx_session_phase1x(infx_session* S, const uint32_t* global_union_counts, void* counts, uint32_t* ndev) {
+    if (!S || !counts) return efail(INFX_EINVAL, "null");
+    static const uint32_t zero = 0;
+    int32_t rc = ph_plan_finish(S->e, S, global_union_counts ? global_union_counts : &zero); if (rc) return rc;
+    Batch& B = *S->batch;
+    S->msAcc = S->msSel = S->msCov = S->msPrep2 = S->msFin = 0; S->algBytes = 0;
+    if (B.nd) {
+        rc = infx_stage1_accumulate(S->stream, B.nd, B.dq.data(), (uint32_t)B.dterms.size(), B.dterms.data(), (uint32_t)B.extra.size(), B.extra.data(), (infx_counts*)counts);
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+    }
+    if (ndev) *ndev = B.nd;
+    return INFX_OK;
+}
 int32_t infx_session_counts(infx_session* S, uint32_t* counts) {   // nd x INFX_NCLASS, this shard
     if (!S || !counts) return efail(INFX_EINVAL, "null");
     std::memcpy(counts, S->batch->counts.data(), S->batch->counts.size() * sizeof(infx_counts)); return INFX_OK;

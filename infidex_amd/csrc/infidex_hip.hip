@@ -765,7 +765,7 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     { int32_t rc_ = acc_enqueue(s, nq, q, nterms, terms, extra_n, extra_docs); if (rc_) return rc_; }
     uint32_t ovf = 0; std::vector<unsigned long long> qbytes(nq);
-    if (counts_out) DOWN(counts_out, s->dCounts, (size_t)nq * INFX_NCLASS * 4);
+    if (counts_out) DOWNX(counts_out, s->dCounts, (size_t)nq * INFX_NCLASS * 4);       // host memory, or a device tensor the caller all-reduces in place
     DOWN(&ovf, s->dOverflow, 4);
     DOWN(qbytes.data(), s->dQBytes, (size_t)nq * 8);
     SYNC();
@@ -1061,7 +1061,7 @@ int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global
     infx_index* ix = s->ix;
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
-    UP(s->dCounts, global_counts, (size_t)nd * INFX_NCLASS * 4);          // the tier rules see the GLOBAL cardinalities (quirk Q11)
+    UPX(s->dCounts, global_counts, (size_t)nd * INFX_NCLASS * 4);         // the tier rules see the GLOBAL cardinalities (quirk Q11); host or device memory
     { int32_t rc_ = fused_enqueue_select(s, nd, depth); if (rc_) return rc_; }
     std::vector<SelRule> rules(nd);
     DOWNX(hits_out, s->dHits, (size_t)nd * depth * sizeof(infx_hit));

@@ -117,7 +117,19 @@ class ShardSession:
         return outs[:self.ncand]
 
     # ---- device-resident exchange buffers (torch CUDA tensors; RCCL works on them in place) ----
+    def phase1_dev(self, global_union_counts, counts_t):
+        """phase 1 with the class histograms written into counts_t (nq x INFX_NCLASS int32 CUDA tensor): Exchange 1 all-reduces it in place."""
+        nd = C.c_uint32(0)
+        guc = np.ascontiguousarray(global_union_counts, np.uint32)
+        if guc.size == 0:
+            guc = np.zeros(1, np.uint32)
+        self.e._check(self.L.infx_session_phase1x(self.s.h, _p(guc, C.c_uint32), C.c_void_p(counts_t.data_ptr()), C.byref(nd)))
+        self.nd = nd.value
+
     def phase2_dev(self, global_counts, hits_t, hc_t):
+        if hasattr(global_counts, "data_ptr"):       # device tensor: read back from HBM by the engine, no host round trip
+            self.e._check(self.L.infx_session_phase2x(self.s.h, C.c_void_p(global_counts.data_ptr()), C.c_void_p(hits_t.data_ptr()), C.c_void_p(hc_t.data_ptr())))
+            return
         gc = np.ascontiguousarray(global_counts, np.uint32)
         if gc.size == 0:
             gc = np.zeros((1, INFX_NCLASS), np.uint32)
@@ -207,11 +219,15 @@ class ShardedSearcher:
         def mark():
             if dbg: T.append(time.time())
         guc = c.allreduce_sum_i32(uc) if uc.size else uc                                          # Exchange 1b: df of new fuzzy unions
-        mark(); counts = s.phase1(guc); mark()
-        gcounts = c.allreduce_sum_i32(counts) if counts.size else counts                       # Exchange 1
         if c.device.type == "cuda" and c.dist.get_backend() == "nccl":
-            # RCCL path: the hit lists and the Stage-2 rows stay in HBM; the collectives run on the tensors the kernels wrote
-            torch = c.torch; nd = max(s.nd, 1); nq = s.nq
+            # RCCL path: class histograms, hit lists and Stage-2 rows stay in HBM; every collective runs in place on the tensor the kernels wrote
+            torch = c.torch; nq = s.nq
+            counts_t = torch.zeros((max(nq, 1), INFX_NCLASS), dtype=torch.int32, device=c.device)
+            torch.cuda.current_stream().synchronize()
+            mark(); s.phase1_dev(guc, counts_t); mark()
+            c.dist.all_reduce(counts_t, op=c.dist.ReduceOp.SUM)                                   # Exchange 1 (tier decisions need GLOBAL cardinalities, Q11)
+            gcounts = counts_t
+            nd = max(s.nd, 1)
             hits_t = torch.zeros((nd, depth, 2), dtype=torch.int32, device=c.device); hc_t = torch.zeros(nd, dtype=torch.int32, device=c.device)
             torch.cuda.current_stream().synchronize()      # the zero fills run on torch's stream, the engine writes on its own: order them
             mark(); s.phase2_dev(gcounts, hits_t, hc_t); mark()
@@ -227,8 +243,10 @@ class ShardedSearcher:
             mark(); r = s.phase4_dev(outs_t); mark()
             if dbg and c.rank == 0:
                 import sys
-                print("[infx-shard] ms: allreduce-uc %.2f phase1 %.2f allreduce-counts+alloc %.2f phase2 %.2f allgather %.2f phase3 %.2f allreduce-rows %.2f phase4 %.2f" % tuple((T[i + 1] - T[i]) * 1e3 for i in range(8)), file=sys.stderr)
+                print("[infx-shard] ms: allreduce-uc+alloc %.2f phase1 %.2f allreduce-counts(device)+alloc %.2f phase2 %.2f allgather %.2f phase3 %.2f allreduce-rows %.2f phase4 %.2f" % tuple((T[i + 1] - T[i]) * 1e3 for i in range(8)), file=sys.stderr)
             return r
+        counts = s.phase1(guc)
+        gcounts = c.allreduce_sum_i32(counts) if counts.size else counts                       # Exchange 1
         hits, hc = s.phase2(gcounts)
         all_hits = c.allgather(hits) if hits.size else hits.reshape((c.world,) + hits.shape)      # Exchange 2 (all-gather of top-k)
         all_hc = c.allgather(hc) if hc.size else hc.reshape((c.world,) + hc.shape)

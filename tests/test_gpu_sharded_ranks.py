@@ -1,0 +1,60 @@
+"""Two real ranks (two processes, torch.distributed gloo, both on GPU 0) run the document-sharded phases with their collectives; the result
+must equal the single-index engine bit for bit (shards cut Stage-1 ties by (score, doc id): the reference engine runs with exact_replay off).
+This is the N>1 path of bench.py / infidex_amd/sharded.py minus RCCL (two ranks cannot share one GPU under RCCL); the RCCL tensors path is
+covered on one GPU by simulate_shards_dev (test_gpu_parity.py / test_gpu_scale.py)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RANK_SCRIPT = r'''
+import os, sys, numpy as np
+import torch, torch.distributed as dist
+torch.cuda.init()
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+from infidex_amd.sharded import create_sharded_engine, ShardedSearcher, TorchComm
+from infidex_amd.engine import pack_texts
+from tools.synth import Synth
+s = Synth(4, docs=120000); arena, offs = s.docs()
+eng = create_sharded_engine(rank, world, 0); eng.index_flat(None, arena, offs, s.field_weights)
+qa, qo = s.queries(300, qseed=91)
+texts = Synth.texts(qa, qo) + ["qu", "", "zzzzqq"]
+searcher = ShardedSearcher(eng, TorchComm(dist))
+a, o = pack_texts(texts)
+batches = [(a, o), pack_texts(texts[:100]), pack_texts(texts[100:])]
+res = list(searcher.search_stream(batches, 20, 500))             # pipelined stream: planner thread + collectives in batch order
+single = searcher.search_packed(a, o, 20, 500)
+if rank == 0:
+    k, sc, t, c, f = res[0]
+    np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f, k1=res[1][0], c1=res[1][3], k2=res[2][0], c2=res[2][3], ks=single[0], cs=single[3])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_equal_the_single_index(tmp_path):
+    from infidex_amd import SearchEngine
+    from infidex_amd.engine import pack_texts
+    from tools.synth import Synth
+    out = str(tmp_path / "r0.npz")
+    env = dict(os.environ); env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["INFX_THREADS"] = "4"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+           "-c", RANK_SCRIPT, out] if False else None
+    script = str(tmp_path / "rank.py"); open(script, "w").write(RANK_SCRIPT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631", script, out]
+    subprocess.run(cmd, check=True, env=env, timeout=900)
+    r = np.load(out)
+    s = Synth(4, docs=120000); arena, offs = s.docs()
+    ref = SearchEngine.create_default(device=0, exact_replay=False); ref.index_flat(None, arena, offs, s.field_weights)
+    qa, qo = s.queries(300, qseed=91)
+    texts = Synth.texts(qa, qo) + ["qu", "", "zzzzqq"]
+    a, o = pack_texts(texts)
+    k, sc, t, c, f = ref.search_packed(a, o, 20)
+    assert np.array_equal(r["c"], c) and np.array_equal(r["k"], k) and np.array_equal(r["sc"], sc) and np.array_equal(r["t"], t) and np.array_equal(r["f"], f)
+    assert np.array_equal(r["cs"], c) and np.array_equal(r["ks"], k)                      # search_packed == search_stream
+    assert np.array_equal(r["k1"], k[:100]) and np.array_equal(r["c1"], c[:100]) and np.array_equal(r["k2"], k[100:]) and np.array_equal(r["c2"], c[100:])
