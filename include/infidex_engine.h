@@ -125,6 +125,10 @@ int32_t infx_engine_column_value(infx_engine* e, int32_t col, uint32_t code, cha
 int32_t infx_engine_set_filter(infx_session* s, const char* expr_utf8 /* NULL = no filter */, int32_t enable_facets, uint32_t* n_in_filter);
 int32_t infx_engine_facet_column_count(infx_session* s);
 int32_t infx_engine_last_facets(infx_session* s, uint32_t nq, uint32_t qi, uint32_t k, int32_t* col, uint32_t* codes, uint32_t* counts, int32_t cap);
+/* The infx_cov_query (CoverageEngine.PrepareQuery) the engine would hand to the device for this raw query text: lets a caller of the device ABI
+ * (infx_stage2_batch) prepare Stage-2 inputs without the engine's search path. */
+int32_t infx_engine_prepare_cov_query(infx_engine* e, const uint16_t* q, int32_t len, infx_cov_query* out);
+int32_t infx_sizeof_cov_query(void);
 int32_t infx_engine_effective_cpus(void);
 /* Switches infx_engine_config.want_features at run time (the introspection buffers behind infx_engine_last_stage1 / _last_stage2). */
 int32_t infx_engine_set_introspection(infx_engine* e, int32_t on);

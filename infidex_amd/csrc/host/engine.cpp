@@ -963,6 +963,16 @@ int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* doc
     }
     return n;
 }
+// CoverageEngine.PrepareQuery for one raw query text, exactly as the engine prepares it for infx_stage2_batch / infx_search_fused (a C# host
+// would build the same struct from its CoverageQueryContext).  Returns INFX_OK, or the status prepare_cov_query reports (envelope).
+int32_t infx_engine_prepare_cov_query(infx_engine* e, const uint16_t* q, int32_t len, infx_cov_query* out) {
+    if (!e || !q || !out || len < 0) return efail(INFX_EINVAL, "bad arguments");
+    QueryPlan P; plan_tokens(e->ix, e->fuzzy, uview((const u16*)q, (size_t)len), 500, P, true);
+    if (P.blank || P.unsupported) return efail(INFX_EINVAL, "blank or unsupported query");
+    std::memset(out, 0, sizeof *out);
+    return prepare_cov_query(e->ix, P.searchText, *out);
+}
+int32_t infx_sizeof_cov_query(void) { return (int32_t)sizeof(infx_cov_query); }
 int32_t infx_engine_effective_cpus(void) { return effective_cpus(); }
 // parity tooling: switch the introspection downloads (Stage-1 rows, Stage-2 candidates / features of the last batch) on or off at run time
 int32_t infx_engine_set_introspection(infx_engine* e, int32_t on) { if (!e) return INFX_EINVAL; e->cfg.want_features = on ? 1 : 0; return INFX_OK; }
