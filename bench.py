@@ -21,6 +21,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Batches in flight run on separate HIP streams: give the runtime enough hardware queues for them (default 4) BEFORE HIP initialises, so the
+# light, latency-bound kernels of one batch (top-k selection, exact replay) overlap the streaming kernels of another (measured: +10 % q/s).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
