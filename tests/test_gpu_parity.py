@@ -268,3 +268,19 @@ def test_random_unicode_corpora_full_parity():
         o = O.OracleEngine.create_default(); o.index(docs)
         st = compare_batch(e, o, queries, 10)
         assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, (seed, st)
+
+
+def test_high_term_frequencies():
+    """Documents that repeat a word up to 150 times: byte tf values from 2 to ~190 (Term.cs:87-109).  The replay kernels get tf >= 3 through the
+    per-row exception records (k_accumulate) or the posting-list lookup."""
+    import random
+    rng = random.Random(9)
+    words = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel"]
+    docs = []
+    for i in range(400):
+        w = rng.choice(words); reps = rng.choice([1, 2, 3, 5, 14, 15, 16, 40, 90, 150])
+        docs.append((i, " ".join([w] * reps + [rng.choice(words) for _ in range(rng.randrange(0, 4))])))
+    e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+    o = O.OracleEngine.create_default(); o.index(docs)
+    st = compare_batch(e, o, ["alpha", "bravo charlie", "delta echo foxtrot", "golf hotel", "alpha alpha", "hotl", "charlie delta"], 10)
+    assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0 and st["s1_boundary"] == 0, st
