@@ -43,7 +43,8 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
                                     int32_t field_count, const int32_t* field_weights);
 
 /* out_keys/out_scores/out_ties: nq x max_results (row-major); out_counts: nq; out_flags (may be NULL): bit0 query needs the
- * short-query path (out of scope, empty result), bit1 coverage stage ran, bit2 coverage returned nothing -> Stage-1 fallback. */
+ * short-query path or exceeds the Stage-2 query envelope (empty result), bit1 coverage stage ran, bit2 coverage returned nothing -> Stage-1
+ * fallback, bit3 at least one candidate document exceeded the Stage-2 envelope (INFX_MAX_DOC_TOKENS tokens) and was left out of the ranking. */
 int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
                                  int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                  uint32_t* out_counts, uint32_t* out_flags);
@@ -113,6 +114,14 @@ int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* doc
                                 int32_t* feat, int64_t cap);
 /* CPUs usable by this process: hardware threads capped by the affinity mask and the cgroup CPU quota (INFX_THREADS overrides);
  * the default size of the host worker pool and of `threads`. */
+/* ---- Document.Deleted ----------------------------------------------------------------------------------------------------------------------
+ * DocumentCollection.DeleteDocumentsByKey (Core/DocumentCollection.cs:200-212): marks every document with one of the keys as deleted; the
+ * index statistics are not rebuilt (as in the reference until the next re-index).  Searches skip deleted documents where the reference does
+ * (Bm25Scorer.cs:322-323,455-459,622-624; SearchPipeline.cs:404-406,463-465,532-537).  Exclusive — no search in flight (the reference's write
+ * lock).  On a sharded engine every rank must make the same call.  *out_marked (optional) = documents newly marked. */
+int32_t infx_engine_delete_documents(infx_engine* e, const int64_t* keys, int64_t n, int64_t* out_marked);
+int32_t infx_engine_restore_documents(infx_engine* e);      /* clears every Deleted flag */
+
 /* ---- Query.Filter (Infiscript, Api/FilterParser.cs) and Query.EnableFacets (config 5) -------------------------------------------------
  * Non-indexed document fields are given as columns (one value per indexed document, in indexing order); the post-filter of the returned
  * rows (Scoring/ResultProcessor.cs:35-70), Filter.NumberOfDocumentsInFilter and the facet counts (Core/FacetBuilder.cs:19-105) run on the

@@ -67,7 +67,16 @@ int32_t infx_upload_postings(infx_index* idx, uint32_t num_terms, const uint64_t
  * Stage-2 text = ToLowerInvariant(TextNormalizer.Normalize(doc.IndexedText)) as UTF-16 (SegmentProcessor.cs:42-75;
  * every Stage-2 comparison in the reference is OrdinalIgnoreCase, so folding once at upload is equivalent). */
 int32_t infx_upload_docs(infx_index* idx, uint32_t num_docs, const float* doc_len, float avgdl,
-                         const int64_t* doc_key, const uint64_t* text_offs /* N+1 */, const uint16_t* text_utf16);
+                         const int64_t* doc_key, const uint8_t* deleted /* N flags (Document.Deleted) or NULL; unsharded indexes only */,
+                         const uint64_t* text_offs /* N+1 */, const uint16_t* text_utf16);
+
+/* Document.Deleted (Core/Document.cs) after the upload: `deleted` holds one flag per GLOBAL internal id (`total_docs` of them — the same array on
+ * every shard; NULL clears all flags).  Nothing else changes, exactly as in the reference between a deletion and the next re-index: postings, df,
+ * doc lengths and avgdl keep the deleted documents.  The query path then skips them where the reference does — a deleted document is scored with
+ * its chunk but never offered to the top-K heap (Bm25Scorer.cs:322-323, 455-459, 622-624), is not scored by Stage 2 (SearchPipeline.cs:463-465), and
+ * a deleted WordMatcher id gets no docIndex (SearchPipeline.cs:532-537) while still counting against the WordMatcher-only limit (:387-397).
+ * Call it while no search is in flight on this index (the reference mutates documents under its write lock). */
+int32_t infx_set_deleted(infx_index* idx, uint32_t total_docs, const uint8_t* deleted);
 
 /* Prefix DocSets (PrefixPostingList.DocSet, Indexing/ShortQuery/PrefixPosting.cs:64,109-137) that prefix precedence
  * can accept (population <= 20*max_depth), CSR over sets; referenced by set index from infx_query.prefix_set. */

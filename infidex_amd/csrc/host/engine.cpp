@@ -12,6 +12,7 @@
 #include "../../../include/infidex_engine.h"
 #include <chrono>
 #include <unordered_map>
+#include <unordered_set>
 #include <cstdio>
 #include <cstdlib>
 
@@ -36,7 +37,7 @@ struct FusedIn;
 struct PerQ {
     std::vector<Entry> stage1;          // consolidated Stage-1 (score desc, key asc)
     std::vector<int32_t> stage1Doc;     // global internal ids
-    bool runCov = false, wmAny = false, done = false;
+    bool runCov = false, wmAny = false, done = false, envelope = false;   // envelope: the query exceeds the Stage-2 query envelope -> answered as unsupported
     uint32_t candOff = 0, candCount = 0; int covIndex = -1;
     int32_t idx0 = -1, idx1 = -1;       // docs with docIndex 0 / 1
 };
@@ -75,6 +76,7 @@ struct infx_engine {
     FuzzyCache fuzzy;
     std::unordered_map<int64_t, int32_t> keyToFirst;
     bool keysAreIds = false;
+    std::vector<uint8_t> deleted;     // Document.Deleted per global internal id; empty = nothing deleted
     int threads = 1;
     infx_session* def = nullptr;      // default session (single-caller API)
     // document sharding: this engine's GPU holds internal ids [shardBase, shardBase + shardN) of the corpus
@@ -136,7 +138,7 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
         HostIndex& ix = e->ix;
         int32_t rc;
         if (e->nranks == 1) {
-            rc = infx_upload_docs(e->dev, (uint32_t)ix.N, ix.docLen.data(), ix.avgdl, ix.docKey.data(), ix.textOff.data(), (const uint16_t*)ix.text.data());
+            rc = infx_upload_docs(e->dev, (uint32_t)ix.N, ix.docLen.data(), ix.avgdl, ix.docKey.data(), nullptr, ix.textOff.data(), (const uint16_t*)ix.text.data());
             if (!rc) rc = infx_upload_postings(e->dev, (uint32_t)ix.terms.K(), ix.terms.off.data(), ix.terms.doc.data(), ix.terms.w.data(), ix.df.data());
             if (!rc) rc = infx_upload_prefix_docsets(e->dev, (uint32_t)(ix.psOff.size() - 1), ix.psOff.data(), ix.psDocs.data());
             if (!rc && ix.cfg.wordMatcher) rc = infx_upload_wordmatcher(e->dev, ix.wmExact.doc.size(), ix.wmExact.doc.data(), ix.wmLd1.doc.size(), ix.wmLd1.doc.data());
@@ -145,7 +147,7 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
             const int32_t sb = e->shardBase, sn = e->shardN, se = sb + sn;
             std::vector<uint64_t> to((size_t)sn + 1);
             for (int32_t d = 0; d <= sn; d++) to[d] = ix.textOff[sb + d] - ix.textOff[sb];
-            rc = infx_upload_docs(e->dev, (uint32_t)sn, ix.docLen.data() + sb, ix.avgdl, ix.docKey.data() + sb, to.data(), (const uint16_t*)ix.text.data() + ix.textOff[sb]);
+            rc = infx_upload_docs(e->dev, (uint32_t)sn, ix.docLen.data() + sb, ix.avgdl, ix.docKey.data() + sb, nullptr, to.data(), (const uint16_t*)ix.text.data() + ix.textOff[sb]);
             size_t T = ix.terms.K();
             std::vector<uint64_t> lo(T), hi(T); e->shardOff.assign(T + 1, 0);
             parallel_for((int64_t)T, e->threads, [&](int64_t b, int64_t en, int) {
@@ -369,11 +371,14 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
             if (wm.any) { wm_contains_batch(wm, sortedTop.data(), (int)sortedTop.size(), hitFlag, sbase); for (size_t z = 0; z < sortedTop.size(); z++) if (hitFlag[z]) overlap.push_back(sortedTop[z]); }   // ascending
             size_t wmLimit = (size_t)std::max(0, depth - (int)overlap.size());
             size_t need = std::max<size_t>(wmLimit, 2);
-            wm_first_unique(wm, sortedTop, need, uniq);
-            // docIndex 0/1 = first two keys in insertion order: Stage-1 docs, then WordMatcher-only ids ascending
+            const uint8_t* del = e->deleted.empty() ? nullptr : e->deleted.data();     // Document.Deleted per global internal id
+            int32_t live[2] = {-1, -1};
+            wm_first_unique(wm, sortedTop, need, uniq, del, (int)std::max<int64_t>(0, 2 - (int64_t)ntop), live);
+            // docIndex 0/1 = first two keys in insertion order: Stage-1 docs, then the (live) WordMatcher-only ids ascending
             int32_t first2[2] = {-1, -1}; int nf = 0;
             for (size_t k = 0; k < ntop && nf < 2; k++) first2[nf++] = Sq.stage1Doc[k];
-            for (size_t k = 0; k < uniq.size() && nf < 2; k++) first2[nf++] = uniq[k];
+            if (!del) { for (size_t k = 0; k < uniq.size() && nf < 2; k++) first2[nf++] = uniq[k]; }
+            else for (int k = 0; k < 2 && nf < 2; k++) if (live[k] >= 0) first2[nf++] = live[k];
             Sq.idx0 = first2[0]; Sq.idx1 = first2[1];
             if (dbg) { long long d = since(tC); nsSel += d; long long cur = nsSelMax.load(); while (d > cur && !nsSelMax.compare_exchange_weak(cur, d)) {} }
             auto tD = tick();
@@ -384,14 +389,15 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
             auto& CL = candLocal[i];
             auto push = [&](int32_t doc, float base) { infx_cov_cand c{}; c.query = 0; c.doc = doc; c.base_score = base; c.want_lcs = (doc == first2[0] || doc == first2[1]) ? 1 : 0; CL.push_back(c); };
             for (int32_t d : overlap) push(d, 0.f);
-            for (size_t k = 0; k < uniq.size() && k < wmLimit; k++) push(uniq[k], 0.f);
+            for (size_t k = 0; k < uniq.size() && k < wmLimit; k++) if (!(del && del[uniq[k]])) push(uniq[k], 0.f);     // a deleted id still uses up its wmLimit slot
             float maxT = ntop ? Sq.stage1[0].score : 1.f;
             for (size_t k = 0; k < ntop; k++) push(Sq.stage1Doc[k], maxT > 0 ? Sq.stage1[k].score / maxT : 0.f);
             if (dbg) nsPush += since(tE);
         }
     });
     if (dbg) fprintf(stderr, "[infx] prep2 cpu-ms: merge %.1f wm %.1f select %.1f (max %.2f) covq %.1f push %.1f | wall %.1f\n", nsMerge / 1e6, nsWm / 1e6, nsSel / 1e6, nsSelMax / 1e6, nsCovQ / 1e6, nsPush / 1e6, now_ms() - B.t2);
-    for (uint32_t i = 0; i < nq; i++) if (covErr[i]) return efail(covErr[i], "query exceeds the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length)");
+    // a query outside the Stage-2 envelope is answered as "unsupported" (empty result, flag bit 0); the rest of the batch is unaffected
+    for (uint32_t i = 0; i < nq; i++) if (covErr[i]) { B.pq[i].runCov = false; B.pq[i].stage1.clear(); B.pq[i].stage1Doc.clear(); B.pq[i].envelope = true; candLocal[i].clear(); }
     std::vector<infx_cov_query> covBatch; std::vector<infx_cov_cand>& cands = S->lastCands;
     size_t ncand = 0;
     for (uint32_t i = 0; i < nq; i++) {
@@ -453,7 +459,7 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
     }
     {   std::atomic<int> bad{0};
         parallel_for((int64_t)outs.size(), threads, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; i++) if (outs[i].status) { bad.store(1); break; } });
-        if (bad.load()) return efail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)");
+        (void)bad;     // rows with a non-zero status are skipped per query in ph_finalize (result flag bit 3)
     }
     B.t4 = now_ms();
     return INFX_OK;
@@ -469,13 +475,14 @@ static int32_t ph_finalize(infx_engine* e, infx_session* S, const infx_cov_out* 
         for (int64_t i = b; i < en; i++) {
             PerQ& Sq = B.pq[i]; const QueryPlan& P = plans[i];
             uint32_t flags = 0; const std::vector<Entry>* res = &Sq.stage1;
-            if (P.unsupported) flags |= 1;
+            if (P.unsupported || Sq.envelope) flags |= 1;
             if (Sq.runCov) {
                 flags |= 2;
                 int maxWordHits = 0; uint8_t hits01[2] = {0, 0}, lcs01[2] = {0, 0};
                 fin.clear();
                 for (uint32_t k = 0; k < Sq.candCount; k++) {
                     const infx_cov_cand& c = cands[Sq.candOff + k]; const infx_cov_out& o = outs[Sq.candOff + k];
+                    if (o.status) { flags |= 8; continue; }          // outside the Stage-2 envelope: left out of this query's ranking
                     maxWordHits = std::max(maxWordHits, o.word_hits_full);
                     for (int z = 0; z < 2; z++) { int32_t dz = z == 0 ? Sq.idx0 : Sq.idx1; if (dz >= 0 && c.doc == dz) { if (hits01[z] == 0) hits01[z] = o.word_hits; if (lcs01[z] == 0) lcs01[z] = o.lcs; } }
                     fin.push_back(Entry{o.score, ix.docKey[c.doc], o.tiebreaker});
@@ -573,7 +580,9 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
             covErr[i] = prepare_cov_query(ix, st, cq[i]);
         }
     });
-    for (uint32_t i = 0; i < nq; i++) if (covErr[i]) return efail(covErr[i], "query exceeds the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length)");
+    // a query outside the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length) is answered as "unsupported" (empty result,
+    // flag bit 0) — it does not fail the other queries of the batch
+    for (uint32_t i = 0; i < nq; i++) if (covErr[i]) { fq[i].flags = INFX_FQ_SKIP | INFX_FQ_UNSUPPORTED; qLists[i].clear(); qOwned[i].clear(); }
     lists.clear(); owned.clear();
     for (uint32_t i = 0; i < nq; i++) {
         fq[i].wm_off = (uint32_t)lists.size(); fq[i].wm_count = (uint32_t)qLists[i].size();
@@ -985,6 +994,32 @@ int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uin
 // raw access for bench.py (HBM-resident inputs are the engine's; these expose the flat host arrays for oracle adoption)
 int32_t infx_engine_device_handles(infx_engine* e, infx_index** idx, infx_stream** st) { if (!e) return INFX_EINVAL; if (idx) *idx = e->dev; if (st) *st = e->def->stream; return INFX_OK; }
 
+
+// ---- Document.Deleted -----------------------------------------------------------------------------------------------------------------
+// DocumentCollection.DeleteDocumentsByKey (Core/DocumentCollection.cs:200-212): every document (alias / segment) with one of the keys is marked
+// deleted.  The index itself is not touched — like the reference between a deletion and the next re-index, df / doc lengths / avgdl still
+// include the document; the query path skips it (include/infidex_hip.h, infx_set_deleted).  Exclusive: no search may be in flight.
+int32_t infx_engine_delete_documents(infx_engine* e, const int64_t* keys, int64_t n, int64_t* out_marked) {
+    if (!e || (n > 0 && !keys)) return efail(INFX_EINVAL, "null argument");
+    if (!e->indexed) return efail(INFX_EINVAL, "delete before index_documents");
+    const int64_t N = e->ix.N; int64_t marked = 0;
+    if (e->deleted.empty()) e->deleted.assign((size_t)N, 0);
+    if (e->keysAreIds) { for (int64_t i = 0; i < n; i++) if (keys[i] >= 0 && keys[i] < N && !e->deleted[(size_t)keys[i]]) { e->deleted[(size_t)keys[i]] = 1; marked++; } }
+    else {
+        std::unordered_set<int64_t> ks(keys, keys + n);
+        for (int64_t d = 0; d < N; d++) if (!e->deleted[(size_t)d] && ks.count(e->ix.docKey[(size_t)d])) { e->deleted[(size_t)d] = 1; marked++; }
+    }
+    if (out_marked) *out_marked = marked;
+    if (e->dev) { int32_t rc = infx_set_deleted(e->dev, (uint32_t)N, e->deleted.data()); if (rc) { g_eerr = infx_last_error(); return rc; } }
+    return INFX_OK;
+}
+// Clears every Deleted flag (what a reload of the undeleted documents would give).
+int32_t infx_engine_restore_documents(infx_engine* e) {
+    if (!e) return efail(INFX_EINVAL, "null argument");
+    e->deleted.clear();
+    if (e->dev && e->indexed) { int32_t rc = infx_set_deleted(e->dev, 0, nullptr); if (rc) { g_eerr = infx_last_error(); return rc; } }
+    return INFX_OK;
+}
 
 // ---- Infiscript post-filter + facets (config 5): Query.Filter / Query.EnableFacets (SearchEngine.cs:298-316) ------------------------------
 // One non-indexed document field for all documents (DocumentFields / Field.Value), by internal id: kind 1 int64, 2 double, 3 UTF-8 strings

@@ -478,22 +478,28 @@ inline void wm_contains_batch(const WmResult& R, const int32_t* q, int m, std::v
     }
 }
 // first `limit` ids of the union in ascending order that are not in `exclude` (sorted)
-inline void wm_first_unique(const WmResult& R, const std::vector<int32_t>& excludeSorted, size_t limit, std::vector<int32_t>& out) {
+// With deletions (del != nullptr): live[0..1] receive the first two ids of that sequence that are not deleted (-1 = none); the walk goes on past
+// `limit` until `wantLive` of them are known (SearchPipeline.cs:532-537: only live WordMatcher ids get a docIndex).
+inline void wm_first_unique(const WmResult& R, const std::vector<int32_t>& excludeSorted, size_t limit, std::vector<int32_t>& out,
+                            const uint8_t* del = nullptr, int wantLive = 0, int32_t* live = nullptr) {
     out.clear();
-    if (limit == 0 || R.lists.empty()) return;
+    int nLive = 0; if (live) { live[0] = -1; live[1] = -1; }
+    if (!del) wantLive = 0;
+    if ((limit == 0 && wantLive == 0) || R.lists.empty()) return;
     using E = std::pair<int32_t, size_t>;   // (doc, list)
     std::priority_queue<E, std::vector<E>, std::greater<E>> pq;
     std::vector<size_t> pos(R.lists.size(), 0);
     for (size_t i = 0; i < R.lists.size(); i++) if (R.lists[i].n) pq.push({R.lists[i].p[0], i});
     int32_t last = -1;
-    while (!pq.empty() && out.size() < limit) {
+    while (!pq.empty() && (out.size() < limit || nLive < wantLive)) {
         E e2 = pq.top(); pq.pop();
         size_t li = e2.second;
         if (++pos[li] < R.lists[li].n) pq.push({R.lists[li].p[pos[li]], li});
         if (e2.first == last) continue;
         last = e2.first;
         if (std::binary_search(excludeSorted.begin(), excludeSorted.end(), e2.first)) continue;
-        out.push_back(e2.first);
+        if (out.size() < limit) out.push_back(e2.first);
+        if (del && live && nLive < 2 && !del[e2.first]) live[nLive++] = e2.first;
     }
 }
 

@@ -41,7 +41,7 @@ struct DevIndex {
     const uint64_t* postOff; const int32_t* postDoc; const uint8_t* postW;
     const float* docNorm;      // K1*((1-B) + (B/avgdl)*dl) — the 8-lane formula of Bm25Scorer.cs:413-416
     const float* docLen;       // VectorModel._docLengths (the scalar-tail formula of ComputeTermScore needs dl / avgdl, k_exact1)
-    const uint8_t* deleted;    // Document.Deleted per shard-local doc (nullptr = none)
+    const uint8_t* deleted;    // Document.Deleted per GLOBAL internal id (nullptr = nothing deleted)
     const int64_t* docKey;
     const uint64_t* textOff; const uint16_t* text;
     const uint32_t* skipIdx;   // per term: first entry in skipTbl, or 0xFFFFFFFF
@@ -66,6 +66,7 @@ struct infx_index {
     std::vector<uint64_t> hPostLen;   // true list lengths
     std::vector<int32_t> hDf;
     std::vector<uint32_t> hSkipIdx;   // host copy of DevIndex::skipIdx (filled by infx_upload_postings)
+    uint8_t* dDeleted = nullptr;      // device copy of the global Document.Deleted flags (infx_set_deleted)
     const uint32_t* colCodes[FILT_MAXCOL] = {}; uint32_t colValues[FILT_MAXCOL] = {}; uint32_t colDocs[FILT_MAXCOL] = {};   // device-resident columns (infx_upload_column)
     std::vector<uint64_t> hPsOff;
     int rank = 0, nranks = 1;
@@ -464,9 +465,26 @@ void infx_destroy(infx_index* ix) {
     delete ix;
 }
 
-int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float avgdl, const int64_t* doc_key,
+int32_t infx_set_deleted(infx_index* ix, uint32_t total, const uint8_t* deleted) {
+    if (!ix) return fail(INFX_EINVAL, "null argument%s");
+    if (!ix->haveDocs) return fail(INFX_EINVAL, "infx_set_deleted before infx_upload_docs%s");
+    if (deleted && total != (uint32_t)ix->d.totalDocs) return fail(INFX_EINVAL, "infx_set_deleted: one flag per global internal id (total_docs) is required%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    if (!deleted) { ix->d.deleted = nullptr; return INFX_OK; }
+    bool any = false; for (uint32_t i = 0; i < total && !any; i++) any = deleted[i] != 0;
+    if (!any) { ix->d.deleted = nullptr; return INFX_OK; }           // the kernels test the pointer: no per-row gather while nothing is deleted
+    if (!ix->dDeleted) HIPCHK(dalloc(ix, &ix->dDeleted, (size_t)total));
+    HIPCHK(hipMemcpy(ix->dDeleted, deleted, (size_t)total, hipMemcpyHostToDevice));
+    ix->d.deleted = ix->dDeleted;
+    return INFX_OK;
+}
+
+int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float avgdl, const int64_t* doc_key, const uint8_t* deleted,
                          const uint64_t* text_offs, const uint16_t* text) {
     if (!ix || !doc_len || !doc_key) return fail(INFX_EINVAL, "null argument%s");
+    if (deleted && (ix->d.docBase != 0 || (ix->d.totalDocs != 0 && ix->d.totalDocs != (int32_t)N)))
+        return fail(INFX_EINVAL, "infx_upload_docs: deleted[] is for unsharded indexes; a shard takes the global flags through infx_set_deleted%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
     float *dLen = nullptr, *dNorm = nullptr; int64_t* dKey = nullptr; uint64_t* dTO = nullptr; uint16_t* dTx = nullptr;
     HIPCHK(dalloc(ix, &dNorm, N)); HIPCHK(dalloc(ix, &dKey, N)); HIPCHK(dalloc(ix, &dLen, N));
@@ -491,6 +509,7 @@ int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float
     if (ix->d.nRanges == 0) ix->d.nRanges = 1;
     if (ix->d.totalDocs == 0) ix->d.totalDocs = (int32_t)N;
     ix->avgdl = avgdl; ix->haveDocs = true;
+    if (deleted) return infx_set_deleted(ix, N, deleted);
     return INFX_OK;
 }
 
@@ -1045,7 +1064,7 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
     if (nd) { DOWN(&ovf, s->dOverflow, 4); DOWN(qbytes.data(), s->dQBytes, (size_t)nd * 8); DOWN(rules.data(), s->dRules, (size_t)nd * sizeof(SelRule)); }
     SYNC();
     if (ovf) return fail(INFX_ECAPACITY, "candidate arena overflow (bound violated)%s");
-    if (err) return fail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)%s");
+    (void)err;     // candidates outside the Stage-2 envelope are skipped per query (result flag bit 3), they no longer fail the batch
     fused_scatter_results(nq, max_results, R, out_keys, out_scores, out_ties, out_counts);
     s->lastAlgBytes = 0; for (auto b : qbytes) s->lastAlgBytes += b;
     s->lastCandTotal = 0; for (auto& r : rules) s->lastCandTotal += r.total;
@@ -1109,7 +1128,7 @@ int32_t infx_shard_finalize(infx_stream* s, uint32_t nq, const infx_cov_out* mer
     uint32_t err = 0; FusedResultStage R;
     { int32_t rc_ = fused_download_results(s, nq, max_results, R, out_ties != nullptr, out_counts, out_flags, &err); if (rc_) return rc_; }
     SYNC();
-    if (err) return fail(INFX_EUNSUPPORTED, "a candidate document exceeds the Stage-2 envelope (INFX_MAX_DOC_TOKENS)%s");
+    (void)err;     // candidates outside the Stage-2 envelope are skipped per query (result flag bit 3), they no longer fail the batch
     fused_scatter_results(nq, max_results, R, out_keys, out_scores, out_ties, out_counts);
     return INFX_OK;
 }

@@ -66,6 +66,7 @@ class Result:      # Api/Result.cs
     unsupported: bool = False
     used_coverage: bool = False
     stage1_fallback: bool = False
+    skipped_candidates: bool = False       # a candidate document exceeded the Stage-2 envelope (INFX_MAX_DOC_TOKENS) and was left out
     facets: Optional[dict] = None          # field -> [(value, count)] (count desc, value asc), Api/Result.cs Facets
     total_in_filter: int = 0               # Filter.NumberOfDocumentsInFilter
 
@@ -172,6 +173,19 @@ class SearchEngine:
                                                        _p(offs, C.c_uint64), len(fw), _p(fw, C.c_int32)))
         self._keep = None
 
+    # ---- Document.Deleted (DocumentCollection.DeleteDocumentsByKey, Core/DocumentCollection.cs:200-212) ----
+    def delete_documents(self, keys) -> int:
+        """Marks every document with one of these DocumentKeys as deleted (index statistics are not rebuilt, as in the reference until the next
+        re-index); returns how many documents were newly marked.  Exclusive: no search may be in flight."""
+        k = np.ascontiguousarray(list(keys) if not isinstance(keys, np.ndarray) else keys, np.int64)
+        marked = C.c_int64(0)
+        self._check(self.L.infx_engine_delete_documents(self.h, _p(k, C.c_int64), C.c_int64(len(k)), C.byref(marked)))
+        return int(marked.value)
+
+    def restore_documents(self):
+        """Clears every Deleted flag."""
+        self._check(self.L.infx_engine_restore_documents(self.h))
+
     # ---- non-indexed document fields (DocumentFields) as columns: filterable / facetable (config 5) ----
     def set_column(self, name, values, facetable=False):
         """One value per indexed document, in indexing order: int64 / float64 numpy array or a sequence of str."""
@@ -219,7 +233,7 @@ class SearchEngine:
                                 vb = C.create_string_buffer(1024); self.L.infx_engine_column_value(self.h, col.value, int(codes[j]), vb, 1024)
                                 vals.append((vb.value.decode(), int(cnts[j])))
                             facets[nb.value.decode()] = vals
-                out.append(Result(recs, bool(flags[i] & 1), bool(flags[i] & 2), bool(flags[i] & 4), facets, int(nin.value)))
+                out.append(Result(recs, bool(flags[i] & 1), bool(flags[i] & 2), bool(flags[i] & 4), bool(flags[i] & 8), facets, int(nin.value)))
             return out
         finally:
             self.L.infx_engine_set_filter(sh, None, 0, None)
@@ -249,7 +263,7 @@ class SearchEngine:
         out = []
         for i in range(len(texts)):
             recs = [ScoreEntry(float(scores[i, k]), int(keys[i, k]), int(ties[i, k])) for k in range(int(counts[i]))]
-            out.append(Result(recs, bool(flags[i] & 1), bool(flags[i] & 2), bool(flags[i] & 4)))
+            out.append(Result(recs, bool(flags[i] & 1), bool(flags[i] & 2), bool(flags[i] & 4), bool(flags[i] & 8)))
         return out
 
     def last_timings(self):

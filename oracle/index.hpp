@@ -77,6 +77,10 @@ struct Index {
     std::unordered_map<uint64_t, int> shortDict;     // len 2..3 fast path (TermCollection.cs:88-118)
     std::vector<float> docLen;
     float avgdl = 0.f;
+    // Document.Deleted (Core/Document.cs): set after indexing.  Postings, df, doc lengths and avgdl are NOT touched (the reference only rebuilds
+    // them on the next full re-index); the query path skips deleted documents at Bm25Scorer.cs:323,456,623 and SearchPipeline.cs:405,464,535.
+    std::vector<uint8_t> deleted;
+    bool is_deleted(int d) const { return !deleted.empty() && deleted[(size_t)d]; }
     std::vector<int> sortedTerms;        // term ids in ordinal string order (trie pre-order)
     std::unordered_map<ustr, float, UHash> wordIdf;   // keys folded with to_upper_inv (OrdinalIgnoreCase dictionary)
     // prefix DocSets: key = packed (len, c0,c1,c2)

@@ -262,6 +262,14 @@ int32_t orc_filter_eval(const char* expr, int32_t nfields, const char* const* na
       catch (const std::exception&) { return -2; }
 }
 int32_t orc_double_to_string(double x, char* out, int32_t cap) { std::string s = flt::dbl_to_string(x); snprintf(out, (size_t)cap, "%s", s.c_str()); return (int32_t)s.size(); }
+// Document.Deleted for every document whose DocumentKey is listed (DocumentCollection.DeleteDocumentsByKey, Core/DocumentCollection.cs:200-212)
+// without the Count bookkeeping: index statistics stay as indexed.  Returns the number of documents newly marked.
+int32_t orc_delete_keys(void* h, const int64_t* keys, int64_t n) {
+    Handle* H = (Handle*)h; Index& ix = H->eng.ix; if (ix.deleted.empty()) ix.deleted.assign((size_t)ix.N, 0);
+    std::unordered_set<int64_t> ks(keys, keys + n); int32_t c = 0;
+    for (int d = 0; d < ix.N; d++) if (!ix.deleted[d] && ks.count(ix.docKey[d])) { ix.deleted[d] = 1; c++; }
+    return c;
+}
 // One column of non-indexed document fields, by internal doc id. kind: 1 int64 (vals_i), 2 double (vals_d), 3 string (arena + offs, UTF-8)
 void orc_set_column(void* h, const char* name, int32_t kind, int32_t facetable, int64_t n, const int64_t* vals_i, const double* vals_d, const char* arena, const uint64_t* offs) {
     Handle* H = (Handle*)h; Column c; c.name = name; c.facetable = facetable != 0; c.vals.resize((size_t)n);

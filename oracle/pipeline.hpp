@@ -136,7 +136,7 @@ struct Engine {
         std::unordered_map<int64_t, int> keyToIndex;
         int next = 0;
         for (auto& c : top) if (keyToIndex.emplace(c.key, next).second) next++;
-        for (int id : wmIds) if (keyToIndex.emplace(ix.docKey[id], next).second) next++;
+        for (int id : wmIds) if (!ix.is_deleted(id) && keyToIndex.emplace(ix.docKey[id], next).second) next++;     // SearchPipeline.cs:532-537
         int nDocs = next;
         uint8_t lcsRow[2] = {0, 0}, hitsRow[2] = {0, 0};   // only docIndex < Height(=2) is ever touched (quirk Q7)
         TopKHeap finalScores(depth);
@@ -149,6 +149,7 @@ struct Engine {
         int wmLimit = std::max(0, depth - (int)overlap.size());
 
         auto process = [&](int internalId, float baseScore) {
+            if (ix.is_deleted(internalId)) return;                 // SearchPipeline.cs:463-465 (a deleted WordMatcher-only id still counts against wmLimit)
             auto kit = keyToIndex.find(ix.docKey[internalId]);
             if (kit == keyToIndex.end()) return;
             int docIndex = kit->second;
@@ -176,7 +177,7 @@ struct Engine {
         for (int id : uniq) { if (done >= wmLimit) break; process(id, 0.f); done++; }
         for (auto& c : top) {
             auto it = ix.keyToFirstId.find(c.key);
-            if (it == ix.keyToFirstId.end()) continue;
+            if (it == ix.keyToFirstId.end() || ix.is_deleted(it->second)) continue;      // SearchPipeline.cs:404-406
             float maxT = !top.empty() ? top[0].score : 1.f;
             float norm = maxT > 0 ? c.score / maxT : 0.f;
             process(it->second, norm);

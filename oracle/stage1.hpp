@@ -366,7 +366,8 @@ struct Stage1 {
                     }
                     for (int c = 0; c < chunk; c++) {
                         float s = scoreBlock[c];
-                        if (s > 0.f) update_topk(docBlock[c], s, topK, heap, threshold);
+                        // Bm25Scorer.cs:318-327: a deleted document is scored with its chunk but never offered to the pruning heap
+                        if (s > 0.f && !ix.is_deleted(docBlock[c])) update_topk(docBlock[c], s, topK, heap, threshold);
                     }
                     processed += chunk;
                 }
@@ -386,6 +387,7 @@ struct Stage1 {
                     if (topK < std::numeric_limits<int>::max() && heap.count() >= topK) {
                         if (cur + terms[t].maxScore + suffix[t + 1] <= threshold) continue;
                     }
+                    if (ix.is_deleted(d)) continue;                 // Bm25Scorer.cs:622-624
                     float tf = p.freq(); if (tf <= 0.f) continue;
                     float dl = ix.docLen[d]; if (dl <= 0.f) dl = 1.f;
                     float ns = cur + term_score_scalar(tf, dl, avgdl, terms[t].idf);

@@ -308,5 +308,12 @@ def _oe_search_filtered(self, text, max_results=10, depth=500, enable_coverage=T
             "in_filter": int(nin.value), "facets": {k: [(a, int(b)) for a, b in v] for k, v in json.loads(buf.value.decode() or "{}").items()}}
 
 
+def _oe_delete_keys(self, keys):
+    """Document.Deleted = true for every document with one of these DocumentKeys (index statistics untouched)."""
+    k = np.ascontiguousarray(keys, np.int64); self.L.orc_delete_keys.restype = C.c_int32
+    return int(self.L.orc_delete_keys(self.h, _p(k, C.c_int64), C.c_int64(len(k))))
+
+
+OracleEngine.delete_keys = _oe_delete_keys
 OracleEngine.set_column = _oe_set_column
 OracleEngine.search_filtered = _oe_search_filtered

@@ -63,7 +63,7 @@ def test_device_abi_with_oracle_built_inputs():
     cfg = Cfg(0, 0, DEPTH, 0)
     chk(L, L.infx_create(C.byref(cfg), C.byref(idx)))
     keys = np.arange(N, dtype=np.int64)
-    chk(L, L.infx_upload_docs(idx, N, _p(ex["doc_len"], C.c_float), C.c_float(avgdl), _p(keys, C.c_int64), _p(toffs, C.c_uint64), _p(text, C.c_uint16)))
+    chk(L, L.infx_upload_docs(idx, N, _p(ex["doc_len"], C.c_float), C.c_float(avgdl), _p(keys, C.c_int64), None, _p(toffs, C.c_uint64), _p(text, C.c_uint16)))
     chk(L, L.infx_upload_postings(idx, T, _p(ex["post_off"], C.c_uint64), _p(ex["post_doc"], C.c_int32), _p(ex["post_w"], C.c_uint8), _p(ex["df"], C.c_int32)))
     z = np.zeros(1, np.uint64)
     chk(L, L.infx_upload_prefix_docsets(idx, 0, _p(z, C.c_uint64), None))

@@ -141,6 +141,47 @@ def test_exact_replay_off_keeps_doc_order_ties(corpus):
     assert same >= 285
 
 
+def test_deleted_documents_at_scale(corpus):
+    """Deletions at 400k documents, through the exact Stage-1 replay: a deleted document keeps its position in the reference's chunks and match
+    lists (so the Vector256 / scalar-tail split of its neighbours is unchanged) but never reaches the heap.  Oracle sample must be identical;
+    the document-sharded pipeline with the same deletions must equal the single index (doc-order ties on both sides)."""
+    from infidex_amd.sharded import create_sharded_engine, ShardSession, simulate_shards_dev
+    s, arena, offs, e, texts = corpus
+    rng = np.random.default_rng(77)
+    sample = texts[160:280]
+    keys0, _, _, counts0, _ = run(e, sample)
+    gone = set(rng.choice(N_DOCS, N_DOCS // 10, replace=False).tolist())
+    for i in range(len(sample)):
+        gone.update(keys0[i, :min(3, int(counts0[i]))].tolist())                    # and the best rows of every sampled query
+    gone = np.asarray(sorted(gone), np.int64)
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    try:
+        assert e.delete_documents(gone) == len(gone) and o.delete_keys(gone) == len(gone)
+        keys, scores, ties, counts, flags = run(e, sample)
+        replays = e.last_timings()["exact_replays"]
+        gs = set(gone.tolist()); differ = 0
+        for i, q in enumerate(sample):
+            got = keys[i, :int(counts[i])].tolist()
+            assert not (set(got) & gs), q
+            r = o.search(q, K, 500)
+            if set(got) != set(r["keys"]):
+                differ += 1; print("differs:", q, got, r["keys"])
+        print("deleted sample:", len(sample) - differ, "identical of", len(sample), "; exact replays", replays)
+        assert differ == 0
+        # shards: same deletions on every rank
+        W = 2
+        engs = [create_sharded_engine(r, W, 0) for r in range(W)]
+        for g in engs:
+            g.index_flat(None, arena, offs, s.field_weights); g.delete_documents(gone)
+        u = SearchEngine.create_default(device=0, exact_replay=False); u.index_flat(None, arena, offs, s.field_weights); u.delete_documents(gone)
+        a2, o2 = pack_texts(texts[:300]); ref = u.search_packed(a2, o2, K)
+        for res in simulate_shards_dev([ShardSession(g) for g in engs], a2, o2, K):
+            for x, y in zip(res, ref):
+                assert np.array_equal(x, y)
+    finally:
+        e.restore_documents()
+
+
 def test_host_phase_implementation_equals_device_pipeline(tmp_path):
     """INFX_PHASED=1 routes a single-GPU engine through the stage-wise C ABI (infx_stage1_accumulate / _select, infx_stage2_batch) with the
     host implementation of tier rules, candidate assembly and final ordering.  It must agree bit for bit with the device pipeline."""
@@ -156,7 +197,14 @@ e = SearchEngine.create_default(device=0); e.index_flat(None, arena, offs, s.fie
 qa, qo = s.queries(300, qseed=9, fuzz=0.3)
 a, o = pack_texts(Synth.texts(qa, qo) + ["qu", "", "zzzzqq"])
 k, sc, t, c, f = e.search_packed(a, o, 10)
-np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f)
+# Stage-2 envelope: an over-long document is skipped per candidate (flag bit 3), an over-long query is answered as unsupported (flag bit 0)
+from infidex_amd import Document
+e2 = SearchEngine.create_default(device=0)
+e2.index_documents([Document(0, " ".join("word%d" % i for i in range(260))), Document(1, "word0 word1"), Document(2, "charlie delta"), Document(3, "word0 word1 charlie")])
+a2, o2 = pack_texts(["word0 word1", "charlie delta", "x" * 300])
+k2, sc2, t2, c2, f2 = e2.search_packed(a2, o2, 5)
+assert f2[0] & 8 and not (f2[1] & 8) and f2[2] & 1 and c2[2] == 0, f2
+np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f, k2=k2, sc2=sc2, c2=c2, f2=f2)
 '''
     outs = []
     for phased in ("0", "1"):
@@ -169,6 +217,9 @@ np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f)
         outs.append(np.load(path))
     a, b = outs
     assert np.array_equal(a["c"], b["c"]) and np.array_equal(a["f"], b["f"])
+    assert np.array_equal(a["c2"], b["c2"]) and np.array_equal(a["f2"], b["f2"])
+    for i in range(3):
+        n = int(a["c2"][i]); assert np.array_equal(a["k2"][i, :n], b["k2"][i, :n]) and np.array_equal(a["sc2"][i, :n], b["sc2"][i, :n])
     for i in range(len(a["c"])):
         n = int(a["c"][i])
         assert np.array_equal(a["k"][i, :n], b["k"][i, :n]) and np.array_equal(a["sc"][i, :n], b["sc"][i, :n]) and np.array_equal(a["t"][i, :n], b["t"][i, :n])

@@ -335,3 +335,23 @@ def test_stop_term_quirk_q5():
     assert ix["df"][e.term_id("zzz")] == -1
     r = e.search("zzz", 10)
     assert r["keys"] == [] or r["keys"] is not None    # stop term silently dropped, no crash
+
+
+def test_deleted_documents_are_skipped_not_reindexed():
+    """Document.Deleted (Core/Document.cs, DocumentCollection.cs:200-212): the flag is checked on the query path only — Bm25Scorer.cs:322-323
+    (flush), SearchPipeline.cs:404-406 / 463-465 (coverage), :532-537 (docIndex).  Index statistics are untouched, so the scores of the
+    surviving documents do not move."""
+    o = O.OracleEngine.create_default(); o.index(TEN_DOCS)
+    before = o.search("batman", 10)
+    assert before["keys"][0] == 6
+    assert o.delete_keys([6]) == 1 and o.delete_keys([6]) == 0
+    after = o.search("batman", 10)
+    assert 6 not in after["keys"]
+    # the other rows keep their scores: df / avgdl still include the deleted document
+    b = dict(zip(before["keys"], before["scores"])); a = dict(zip(after["keys"], after["scores"]))
+    assert all(abs(a[k] - b[k]) < 1e-6 for k in a if k in b)
+    # a WordMatcher-only hit (typo query) on a deleted document disappears as well
+    assert o.search("battamam", 10)["keys"] == []
+    r = o.search("qick fux", 10)["keys"]
+    o.delete_keys(r[:1])
+    assert o.search("qick fux", 10)["keys"] == r[1:]
