@@ -278,10 +278,12 @@ static int32_t grow(void** p, size_t* cap, size_t need) {
 
 // Stage-2 launches: the register budget of the fast variant is selectable for tuning (INFX_S2_WAVES = 2, 4 or 6 waves per SIMD)
 static int s2_waves() { static const int w = [] { const char* e = getenv("INFX_S2_WAVES"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4 || v == 6 || v == 8) ? v : S2_MIN_WAVES; }(); return w; }
-#define S2_GRID (ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, 0, s->st
-#define S2_LAUNCH_FAST(...) do { switch (s2_waves()) { case 2: k_stage2<S2_FASTD, 2><<<S2_GRID>>>(__VA_ARGS__); break; case 6: k_stage2<S2_FASTD, 6><<<S2_GRID>>>(__VA_ARGS__); break; case 8: k_stage2<S2_FASTD, 8><<<S2_GRID>>>(__VA_ARGS__); break; \
-                                                     default: k_stage2<S2_FASTD, 4><<<S2_GRID>>>(__VA_ARGS__); break; } } while (0)
-#define S2_LAUNCH_SLOW(...) k_stage2<S2_MAXD, 4><<<S2_GRID>>>(__VA_ARGS__)
+// LDS pool of the fast launch: UTF-16 units of document text per 64-candidate workgroup (INFX_S2_POOL overrides; 0 = texts stay in global memory)
+static int s2_pool() { static const int w = [] { const char* e = getenv("INFX_S2_POOL"); int v = e ? atoi(e) : S2_POOL_CHARS; return (v < 0 || v > 32768) ? S2_POOL_CHARS : v; }(); return w; }
+#define S2_GRID(lds) (ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, (lds), s->st
+#define S2_LAUNCH_FAST(...) do { const int pool_ = s2_pool(); switch (s2_waves()) { case 2: k_stage2<S2_FASTD, 2><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; case 6: k_stage2<S2_FASTD, 6><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; \
+                                                     case 8: k_stage2<S2_FASTD, 8><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; default: k_stage2<S2_FASTD, 4><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; } } while (0)
+#define S2_LAUNCH_SLOW(...) k_stage2<S2_MAXD, 4><<<S2_GRID(0)>>>(__VA_ARGS__, 0)
 
 // ---- host <-> device transfers through pinned staging -------------------------------------------------------------------
 // The C ABI takes plain (pageable) host pointers.  Handing those to hipMemcpyAsync makes the runtime pin/unpin the caller's pages
