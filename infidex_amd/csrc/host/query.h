@@ -520,7 +520,6 @@ inline int32_t prepare_cov_query(const HostIndex& ix, uview query, infx_cov_quer
     C.num_tokens = (int)uq.size();
     const int n = ix.cfg.ngram;
     for (int i = 0; i < (int)uq.size(); i++) {
-        if (uq[i].len > 62) return INFX_EUNSUPPORTED;
         C.tok_off[i] = (uint16_t)uq[i].off; C.tok_len[i] = (uint16_t)uq[i].len;
         uview term = query.substr(uq[i].off, uq[i].len);
         float sum = 0.f; int cnt = 0;

@@ -228,6 +228,31 @@ def test_long_documents_take_the_retry_launch():
         assert r[2].unsupported and not r[2].records, path     # a query beyond INFX_MAX_QUERY_CHARS is answered as unsupported, not as a batch failure
 
 
+def test_long_tokens_have_no_length_limit():
+    """Tokens far longer than any fixed cost row: the Levenshtein band (k_stage2) lives in registers, so 70-150 character words in documents
+    and queries (exact, one typo, prefix, joined) are scored like the reference does — no envelope on the token length any more."""
+    import random
+    rng = random.Random(5)
+    alpha = "abcdefghijklmnopqrstuvwxyz"
+    longw = ["".join(rng.choice(alpha) for _ in range(n)) for n in (70, 85, 100, 120, 150, 64, 63, 65)]
+    docs = []
+    for i in range(120):
+        ws = [rng.choice(longw) for _ in range(rng.choice([1, 2, 3]))] + [rng.choice(["alpha", "bravo", "charlie", "delta"]) for _ in range(rng.choice([0, 1, 2]))]
+        rng.shuffle(ws)
+        docs.append((i, " ".join(ws)))
+    e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+    o = O.OracleEngine.create_default(); o.index(docs)
+
+    def typo(w):
+        p = rng.randrange(5, len(w) - 5); return w[:p] + ("x" if w[p] != "x" else "y") + w[p + 1:]
+    qs = [longw[0], longw[1] + " alpha", typo(longw[2]), typo(longw[3]) + " bravo", longw[4][:90], longw[0] + longw[1], typo(longw[5]), longw[6] + " " + typo(longw[7]),
+          longw[2][:60] + " " + longw[3][:40]]
+    qs = [q for q in qs if len(q) <= 250]
+    st = compare_batch(e, o, qs, 10)
+    assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0 and st["s1_boundary"] == 0, st
+    assert not any(r.unsupported or r.skipped_candidates for r in e.search_batch(qs, 10))
+
+
 def test_deleted_documents_are_skipped_like_the_reference():
     """Document.Deleted after indexing (DocumentCollection.DeleteDocumentsByKey): postings / df / avgdl keep the document, the query path skips
     it — never in the Stage-1 heap (Bm25Scorer.cs:322-323), never scored by Stage 2 (SearchPipeline.cs:463-465), no docIndex for a deleted
