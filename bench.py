@@ -233,6 +233,12 @@ def main():
             a1, o1 = pack_texts([q1])
             t1 = time.time(); sessions[0].search_packed(a1, o1, k, 500); ls.append((time.time() - t1) * 1000.0)
         single_ms = float(np.median(ls[8:]))
+    STAGE_KEYS = ("plan_ms", "stage1_ms", "prep2_ms", "stage2_ms", "post_ms", "k_accumulate_ms", "k_select_ms", "k_prep2_ms", "k_stage2_ms", "k_finalize_ms")
+    stage_me = {kk: float(np.mean([t[kk] for t in tim])) for kk in STAGE_KEYS}
+    stage_ranks = None
+    if dist is not None and world > 1:          # per-phase milliseconds of EVERY rank (host phases are replicated, device phases shrink with W)
+        stage_ranks = [None] * world
+        dist.all_gather_object(stage_ranks, stage_me)
     acc_ms = float(np.mean([t["k_accumulate_ms"] for t in roof]))
     alg = float(np.mean([t["alg_bytes"] for t in roof]))
     streamed = float(np.mean([t["streamed_bytes"] for t in roof]))
@@ -254,8 +260,7 @@ def main():
         # host phases of a batch (per session; sessions overlap): planning (text prep, term lookup, LD1 expansion, idf/roles),
         # Stage-1 host part (phase API only), Stage-2 preparation (fused pipeline: WordMatcher descriptors + PrepareQuery),
         # the wait for the device (fused: the whole device pipeline behind one synchronisation), host post-processing
-        "stage_ms_per_step": {kk: float(np.mean([t[kk] for t in tim])) for kk in ("plan_ms", "stage1_ms", "prep2_ms", "stage2_ms", "post_ms",
-                                                                                  "k_accumulate_ms", "k_select_ms", "k_prep2_ms", "k_stage2_ms", "k_finalize_ms")},
+        "stage_ms_per_step": stage_me,
         "roofline": {"kernel": "k_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "limiter": "not bandwidth: LDS scatter/probe round trips and instruction issue of one wave per (query, doc range); the batch shares "
@@ -267,6 +272,8 @@ def main():
                      "note": "achieved = SURVEY 8(d) algorithmic bytes / k_accumulate duration (HIP events on the launch stream, uncontended launch)"},
         "setup_s": {"corpus_gen": t_gen, "index_build_and_upload": t_index, "host_threads": bthreads},
     }
+    if stage_ranks is not None:
+        out["stage_ms_per_step_per_rank"] = stage_ranks
     if flt and not sharded:
         out["config"]["filter"] = flt; out["config"]["facets"] = ["year", "genre"]
         out["filter"] = {"documents_in_filter": in_filter, "first_use_s_incl_compile_and_device_count": t_filter_first_use}
