@@ -40,7 +40,9 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--range-docs", type=int, default=0)
     ap.add_argument("--build-threads", type=int, default=0)
-    ap.add_argument("--sessions", type=int, default=4, help="batches in flight (host threads, one engine session each)")
+    # measured at 10 M docs (queries/s, p50 / p95 batch latency ms): 4: 53.3 k, 48 / 106; 5: 63.9 k, 60 / 119; 6: 65.9 k, 85 / 126; 7: 66.2 k, 76 / 177; 8: 59.1 k, 86 / 375 —
+    # the replay kernels of a batch run one workgroup per flagged query and leave most CUs to other batches' full-width kernels
+    ap.add_argument("--sessions", type=int, default=6, help="batches in flight (host threads, one engine session each)")
     ap.add_argument("--distinct-batches", type=int, default=24, help="distinct synthetic query batches; the timed steps cycle through them")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent full-index replicas instead of document shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
