@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)      # >= 3 s of timed GPU work at ~20 ms per 1000-query batch
+    ap.add_argument("--steps", type=int, default=256)      # >= 3 s of timed GPU work at ~14 ms per 1000-query batch
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--docs", type=int, default=0, help="0 = the full size of the config (config 4: 10 M)")
     ap.add_argument("--batch", type=int, default=1000)
