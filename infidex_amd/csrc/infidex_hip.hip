@@ -250,6 +250,7 @@ struct infx_stream {
     void* dCovO = nullptr; size_t capCovO = 0;
     void* dCovF = nullptr; size_t capCovF = 0;
     int32_t* arDoc = nullptr; float* arScore = nullptr; uint8_t* arCls = nullptr; size_t arCap = 0;
+    bool accLayoutBad = false;
     unsigned long long* arMask = nullptr; size_t arMaskCap = 0; int maskWords = 0;     // per-row hit masks of the last accumulate launch
     uint32_t* arExc = nullptr; uint32_t* exCand = nullptr; infx_hit* exOut = nullptr; size_t exCap = 0;       // tf exception records, candidate lists, replay rows (arena-sized)
     void* exChunks = nullptr; size_t capExChunks = 0; void* exQueries = nullptr; size_t capExQueries = 0; void* exTasks = nullptr; size_t capExTasks = 0; uint32_t* exCounters = nullptr;
@@ -379,7 +380,18 @@ static Arena make_arena(infx_stream* s) {
                  (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes, (uint2*)s->dDir, s->maskWords};
 }
 static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX_ACC_STRIPE"); int x = e ? atoi(e) : 0; return (x >= 1 && x <= 64) ? x : 4; }(); return v; }
+// LDS8 (stage1.hip.inc) addresses the tf array by raw LDS offset: true only while k_accumulate owns no static __shared__ data, i.e. its dynamic
+// LDS starts at address 0.  Checked once per instantiation against the code object; a violation fails the search loudly.
+template <int R> static bool acc_lds_layout_ok() {
+    static const bool ok = [] {
+        hipFuncAttributes a1{}, a2{};
+        if (hipFuncGetAttributes(&a1, (const void*)k_accumulate<R, 1>) != hipSuccess || hipFuncGetAttributes(&a2, (const void*)k_accumulate<R, 2>) != hipSuccess) return false;
+        return a1.sharedSizeBytes == 0 && a2.sharedSizeBytes == 0;
+    }();
+    return ok;
+}
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp) {
+    if (!acc_lds_layout_ok<R>()) { s->accLayoutBad = true; return; }
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
     const int stripe = acc_stripe();
     const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
@@ -769,6 +781,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
         case 8192: launch_acc<8192>(s, nq, ar, maxT, useGrp); break;
         default: launch_acc<16384>(s, nq, ar, maxT, useGrp); break;
     }
+    if (s->accLayoutBad) return fail(INFX_EHIP, "k_accumulate was built with static LDS: its byte addressing (LDS8) is invalid%s");
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evA1, s->st));
     s->timedAcc = true;
