@@ -139,6 +139,16 @@ int32_t infx_engine_last_facets(infx_session* s, uint32_t nq, uint32_t qi, uint3
 int32_t infx_engine_prepare_cov_query(infx_engine* e, const uint16_t* q, int32_t len, infx_cov_query* out);
 int32_t infx_sizeof_cov_query(void);
 int32_t infx_engine_effective_cpus(void);
+/* Sharded planning: rank r computes the index-wide host lookups (LD1 expansions, WordMatcher descriptors) for queries [begin, end) of the coming
+ * batch; the ranks exchange the serialised results (all-gather of byte blobs) and import each other's before infx_session_phase0.  collect returns
+ * the blob size (or -1), blob copies it out, import takes a peer's blob.  Results are identical with or without the exchange. */
+int64_t infx_session_prefetch_collect(infx_session* s, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, uint32_t begin, uint32_t end, int32_t depth);
+int32_t infx_session_prefetch_blob(infx_session* s, uint8_t* out, int64_t cap);
+int32_t infx_session_prefetch_import(infx_session* s, const uint8_t* blob, int64_t len);
+int64_t infx_session_prefetch_pending(infx_session* s);        /* imported WordMatcher descriptor sets waiting for the next phase 0 */
+/* Measurement hook (no device needed): single-threaded host planning cost of a batch by stage, microseconds per query:
+ * out_us[0] plan_tokens, [1] of it LD1 walks, [2] plan_finish, [3] wm_collect, [4] prepare_cov_query. */
+int32_t infx_engine_host_plan_profile(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, double* out_us);
 /* Switches infx_engine_config.want_features at run time (the introspection buffers behind infx_engine_last_stage1 / _last_stage2). */
 int32_t infx_engine_set_introspection(infx_engine* e, int32_t on);
 int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uint16_t* out, int32_t cap);

@@ -11,6 +11,7 @@
 #include <mutex>
 #include "../../../include/infidex_engine.h"
 #include <chrono>
+#include <map>
 #include <unordered_map>
 #include <unordered_set>
 #include <cstdio>
@@ -63,6 +64,11 @@ struct infx_session {
     std::vector<QueryPlan> lastPlans;
     std::vector<infx_hit> lastHits; std::vector<uint32_t> lastHitCount; int lastStride = 0;
     std::vector<infx_cov_cand> lastCands; std::vector<infx_cov_out> lastOuts; std::vector<int32_t> lastFeat;
+    // sharded planning (infx_session_prefetch_*): WordMatcher descriptors of the coming batch computed by peer ranks, keyed by the search text;
+    // this rank's own share, serialised for the exchange
+    struct WmPre { std::vector<infx_wm_list> lists; std::vector<int32_t> owned; };
+    std::unordered_map<std::u16string, WmPre> wmPre;
+    std::vector<uint8_t> prefetchBlob;
 };
 
 struct CompiledFilter { infx_filter* dev = nullptr; uint32_t inFilter = 0; bool counted = false; };
@@ -84,6 +90,15 @@ struct infx_engine {
     std::vector<uint64_t> shardOff;   // sharded: per-term slice lengths prefix (T+1) of the uploaded CSR
     uint64_t shardTermLen(int32_t t) const { return nranks > 1 ? shardOff[t + 1] - shardOff[t] : ix.terms.len((uint32_t)t); }
 };
+
+// byte-blob writer / reader of the sharded-planning exchange (infx_session_prefetch_*)
+namespace {
+struct BlobW { std::vector<uint8_t>& b; template <class T> void put(const T& v) { const uint8_t* p = (const uint8_t*)&v; b.insert(b.end(), p, p + sizeof(T)); }
+               void bytes(const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; b.insert(b.end(), q, q + n); } };
+struct BlobR { const uint8_t* p; const uint8_t* e; bool ok = true;
+               template <class T> T get() { T v{}; if ((size_t)(e - p) < sizeof(T)) { ok = false; return v; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+               const uint8_t* take(size_t n) { if ((size_t)(e - p) < n) { ok = false; return nullptr; } const uint8_t* r = p; p += n; return r; } };
+}
 
 extern "C" {
 
@@ -534,6 +549,33 @@ static int32_t ph_finalize(infx_engine* e, infx_session* S, const infx_cov_out* 
 
 // Per-query inputs of the device pipeline that need the host dictionaries: flags, WordMatcher list descriptors (WordMatcher.Lookup,
 // WordMatcher.cs:95-186; affix hits are copied into `owned`), CoverageEngine.PrepareQuery.
+// The WordMatcher lists of one search text as device descriptors: (src 0 exact / 1 symmetric-delete dictionary, offset, length) into the uploaded
+// doc-id arrays, affix hits (src 2) copied into `owned`.  A pure function of (index, text): document shards compute it for a slice of the batch each
+// and exchange the results (infx_session_prefetch_*).
+static void wm_descriptors(const HostIndex& ix, const ustr& st, WmResult& wm, std::vector<infx_wm_list>& lists, std::vector<int32_t>& owned) {
+    const int32_t* exB = ix.wmExact.doc.data(); const int32_t* exE = exB + ix.wmExact.doc.size();
+    const int32_t* l1B = ix.wmLd1.doc.data(); const int32_t* l1E = l1B + ix.wmLd1.doc.size();
+    lists.clear(); owned.clear();
+    wm_collect(ix, st, true, wm);
+    for (auto& l : wm.lists) {
+        if (!l.n) continue;
+        infx_wm_list L{}; L.len = (uint32_t)l.n;
+        if (l.p >= exB && l.p < exE) { L.src = 0; L.off = (uint64_t)(l.p - exB); }
+        else if (l.p >= l1B && l.p < l1E) { L.src = 1; L.off = (uint64_t)(l.p - l1B); }
+        else { L.src = 2; L.off = owned.size(); owned.insert(owned.end(), l.p, l.p + l.n); }
+        lists.push_back(L);
+    }
+    if (lists.size() > INFX_MAX_WM_LISTS) {
+        // very long queries: the device probes at most INFX_MAX_WM_LISTS lists per query, so the lists are merged here into ONE
+        // ascending list (membership in any list / first-unique over the union are unchanged by the merge)
+        std::vector<int32_t> all;
+        for (auto& l : wm.lists) all.insert(all.end(), l.p, l.p + l.n);
+        std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
+        owned.swap(all);
+        infx_wm_list L{}; L.src = 2; L.off = 0; L.len = (uint32_t)owned.size();
+        lists.assign(1, L);
+    }
+}
 struct FusedIn { std::vector<infx_fused_query> fq; std::vector<infx_cov_query> cq; std::vector<infx_wm_list> lists; std::vector<int32_t> owned; };
 static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_results, int32_t enable_coverage, FusedIn& F) {
     Batch& B = *S->batch; const HostIndex& ix = e->ix; const int threads = e->threads; const uint32_t nq = B.nq;
@@ -543,8 +585,6 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
     fq.assign(nq, infx_fused_query{}); cq.assign(nq, infx_cov_query{});
     std::vector<std::vector<infx_wm_list>> qLists(nq); std::vector<std::vector<int32_t>> qOwned(nq);
     std::vector<int32_t> covErr(nq, 0);
-    const int32_t* exB = ix.wmExact.doc.data(); const int32_t* exE = exB + ix.wmExact.doc.size();
-    const int32_t* l1B = ix.wmLd1.doc.data(); const int32_t* l1E = l1B + ix.wmLd1.doc.size();
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         WmResult wm;
         for (int64_t i = b; i < en; i++) {
@@ -558,25 +598,9 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
             if (isShort) { F.flags |= INFX_FQ_SHORT; int64_t pk = ix.prefixKeys.find(st); int shortCount = pk >= 0 ? (int)ix.prefixPop[pk] : 0; if (shortCount > 500) F.flags |= INFX_FQ_SHORTSKIP; }
             if (!covEnabled || (F.flags & INFX_FQ_SHORTSKIP)) continue;
             F.flags |= INFX_FQ_COV;
-            wm_collect(ix, st, true, wm);
-            for (auto& l : wm.lists) {
-                if (!l.n) continue;
-                infx_wm_list L{}; L.len = (uint32_t)l.n;
-                if (l.p >= exB && l.p < exE) { L.src = 0; L.off = (uint64_t)(l.p - exB); }
-                else if (l.p >= l1B && l.p < l1E) { L.src = 1; L.off = (uint64_t)(l.p - l1B); }
-                else { L.src = 2; L.off = qOwned[i].size(); qOwned[i].insert(qOwned[i].end(), l.p, l.p + l.n); }
-                qLists[i].push_back(L);
-            }
-            if (qLists[i].size() > INFX_MAX_WM_LISTS) {
-                // very long queries: the device probes at most INFX_MAX_WM_LISTS lists per query, so the lists are merged here into ONE
-                // ascending list (membership in any list / first-unique over the union are unchanged by the merge)
-                std::vector<int32_t> all;
-                for (auto& l : wm.lists) all.insert(all.end(), l.p, l.p + l.n);
-                std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
-                qOwned[i].swap(all);
-                infx_wm_list L{}; L.src = 2; L.off = 0; L.len = (uint32_t)qOwned[i].size();
-                qLists[i].assign(1, L);
-            }
+            auto pre = S->wmPre.find(st);            // computed by a peer rank (sharded planning): same index, same text, same descriptors
+            if (pre != S->wmPre.end()) { qLists[i] = pre->second.lists; qOwned[i] = pre->second.owned; }
+            else wm_descriptors(ix, st, wm, qLists[i], qOwned[i]);
             covErr[i] = prepare_cov_query(ix, st, cq[i]);
         }
     });
@@ -591,6 +615,7 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
         owned.insert(owned.end(), qOwned[i].begin(), qOwned[i].end());
     }
     if (owned.size() > 0xFFFFFFF0ull) return efail(INFX_ECAPACITY, "affix matches of this batch exceed 2^32 ids; split the batch");
+    S->wmPre.clear();
     return INFX_OK;
 }
 
@@ -727,6 +752,81 @@ int32_t infx_session_phase0(infx_session* S, uint32_t nq, const uint16_t* q_aren
         S->batch->pre = std::make_shared<FusedIn>();
         rc = build_fused_inputs(S->e, S, 1, 1, *S->batch->pre); if (rc) return rc;
     }
+    return INFX_OK;
+}
+// ---- sharded planning: the two expensive, index-wide host lookups of a batch — the LD1 expansion of unknown words (plan_tokens) and the
+// WordMatcher dictionary / affix lookups (wm_collect), together ~85 % of the host time per query at 10 M documents — are pure functions of
+// (index, text) and every rank holds the whole host index.  Rank r therefore computes them for queries [begin, end) of the coming batch only,
+// the ranks all-gather the serialised results and import each other's share before phase 0, which then finds every LD1 expansion in the fuzzy
+// cache and every descriptor list in the session (infidex_amd/sharded.py: ShardedSearcher._prefetch, on its own process group).
+// Blob: u32 nLd1 { u16 len, u16 chars[len], u32 n, i32 members[n] }*  u32 nWm { u16 len, u16 chars[len], u32 nl, {u32 src, u32 len, u64 off}[nl], u32 no, i32 owned[no] }*
+int64_t infx_session_prefetch_collect(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, uint32_t begin, uint32_t end, int32_t depth) {
+    if (!S || (nq && (!q_arena || !q_offs)) || begin > end || end > nq) { efail(INFX_EINVAL, "bad arguments"); return -1; }
+    infx_engine* e = S->e; const HostIndex& ix = e->ix; const uint32_t n = end - begin;
+    std::vector<QueryPlan> plans(n);
+    std::vector<std::vector<infx_wm_list>> qL(n); std::vector<std::vector<int32_t>> qO(n);
+    parallel_dyn(n, e->threads, 1, [&](int64_t b, int64_t en, int) {
+        WmResult wm;
+        for (int64_t i = b; i < en; i++) {
+            const uint32_t q = begin + (uint32_t)i;
+            plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[q], (size_t)(q_offs[q + 1] - q_offs[q])), depth, plans[i], false);
+            if (!plans[i].blank && !plans[i].unsupported && ix.cfg.enableCoverage) wm_descriptors(ix, plans[i].searchText, wm, qL[i], qO[i]);
+        }
+    });
+    std::vector<uint8_t>& blob = S->prefetchBlob; blob.clear(); BlobW W{blob};
+    std::map<std::u16string, const FuzzyUnion*> words;          // ordered: the blob is a deterministic function of (index, slice)
+    for (auto& P : plans) for (auto& r : P.rawTok) if (r.fz) words.emplace(r.text, r.fz.get());
+    W.put<uint32_t>((uint32_t)words.size());
+    for (auto& kv : words) {
+        W.put<uint16_t>((uint16_t)kv.first.size()); W.bytes(kv.first.data(), kv.first.size() * 2);
+        W.put<uint32_t>((uint32_t)kv.second->members.size()); W.bytes(kv.second->members.data(), kv.second->members.size() * 4);
+    }
+    std::map<std::u16string, uint32_t> texts;
+    for (uint32_t i = 0; i < n; i++) if (!plans[i].blank && !plans[i].unsupported && ix.cfg.enableCoverage && plans[i].searchText.size() <= 0xFFFF) texts.emplace(plans[i].searchText, i);
+    W.put<uint32_t>((uint32_t)texts.size());
+    for (auto& kv : texts) {
+        const uint32_t i = kv.second;
+        W.put<uint16_t>((uint16_t)kv.first.size()); W.bytes(kv.first.data(), kv.first.size() * 2);
+        W.put<uint32_t>((uint32_t)qL[i].size());
+        for (auto& L : qL[i]) { W.put<uint32_t>(L.src); W.put<uint32_t>(L.len); W.put<uint64_t>(L.off); }
+        W.put<uint32_t>((uint32_t)qO[i].size()); W.bytes(qO[i].data(), qO[i].size() * 4);
+    }
+    return (int64_t)blob.size();
+}
+int64_t infx_session_prefetch_pending(infx_session* S) { return S ? (int64_t)S->wmPre.size() : -1; }
+int32_t infx_session_prefetch_blob(infx_session* S, uint8_t* out, int64_t cap) {
+    if (!S || !out || cap < (int64_t)S->prefetchBlob.size()) return efail(INFX_EINVAL, "bad arguments");
+    std::memcpy(out, S->prefetchBlob.data(), S->prefetchBlob.size()); return INFX_OK;
+}
+int32_t infx_session_prefetch_import(infx_session* S, const uint8_t* blob, int64_t len) {
+    if (!S || !blob || len < 8) return efail(INFX_EINVAL, "bad arguments");
+    infx_engine* e = S->e; const HostIndex& ix = e->ix;
+    BlobR R{blob, blob + len};
+    const uint32_t nw = R.get<uint32_t>();
+    for (uint32_t k = 0; k < nw && R.ok; k++) {
+        const uint16_t wl = R.get<uint16_t>(); const uint8_t* wp = R.take((size_t)wl * 2);
+        const uint32_t nm = R.get<uint32_t>(); const uint8_t* mp = R.take((size_t)nm * 4);
+        if (!R.ok) break;
+        std::u16string word((size_t)wl, u'\0'); std::memcpy(&word[0], wp, (size_t)wl * 2);
+        if (e->fuzzy.get(word)) continue;
+        auto nf = std::make_shared<FuzzyUnion>(); nf->members.resize(nm); if (nm) std::memcpy(nf->members.data(), mp, (size_t)nm * 4);
+        for (int32_t id : nf->members) if (id < 0 || (size_t)id >= ix.df.size()) return efail(INFX_EINVAL, "prefetch blob: term id out of range (ranks must hold the same index)");
+        if (nf->members.empty()) nf->df.store(0);
+        e->fuzzy.put(word, nf);
+    }
+    const uint32_t nt = R.ok ? R.get<uint32_t>() : 0;
+    for (uint32_t k = 0; k < nt && R.ok; k++) {
+        const uint16_t tl = R.get<uint16_t>(); const uint8_t* tp = R.take((size_t)tl * 2);
+        const uint32_t nl = R.get<uint32_t>();
+        infx_session::WmPre pre; pre.lists.resize(nl);
+        for (uint32_t j = 0; j < nl && R.ok; j++) { pre.lists[j] = infx_wm_list{}; pre.lists[j].src = R.get<uint32_t>(); pre.lists[j].len = R.get<uint32_t>(); pre.lists[j].off = R.get<uint64_t>(); }
+        const uint32_t no = R.get<uint32_t>(); const uint8_t* op = R.take((size_t)no * 4);
+        if (!R.ok) break;
+        pre.owned.resize(no); if (no) std::memcpy(pre.owned.data(), op, (size_t)no * 4);
+        std::u16string text((size_t)tl, u'\0'); std::memcpy(&text[0], tp, (size_t)tl * 2);
+        S->wmPre.emplace(std::move(text), std::move(pre));
+    }
+    if (!R.ok) return efail(INFX_EINVAL, "prefetch blob truncated");
     return INFX_OK;
 }
 int32_t infx_session_union_counts(infx_session* S, uint32_t* counts) {   // this shard's |union| of every pending fuzzy virtual term
@@ -930,6 +1030,30 @@ int32_t infx_engine_plan(infx_engine* e, const uint16_t* q, int32_t len, int32_t
     }
     if (meta) { meta[0] = P.q.mode; meta[1] = P.q.prefix_set; meta[2] = P.q.n_and; meta[3] = P.q.df_s1; meta[4] = P.q.df_s2; }
     return n;
+}
+// Host planning profile (measurement hook, no device needed): the per-query host work of a batch, single-threaded, by stage, in microseconds
+// per query: [0] plan_tokens (text preparation, term lookups, LD1 expansion), [1] of that: LD1 walks, [2] plan_finish (idf, roles, modes),
+// [3] wm_collect (WordMatcher descriptors), [4] prepare_cov_query.  Pending fuzzy unions get a stand-in df (their member count).
+int32_t infx_engine_host_plan_profile(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, double* out_us) {
+    if (!e || !out_us || (nq && (!q_arena || !q_offs))) return efail(INFX_EINVAL, "null argument");
+    const HostIndex& ix = e->ix; FuzzyCache fc;
+    std::vector<QueryPlan> plans(nq);
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < nq; i++) plan_tokens(ix, fc, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i], false);
+    auto t1 = std::chrono::steady_clock::now();
+    for (auto& P : plans) for (auto& r : P.rawTok) if (r.fz && r.fz->df.load() < 0) r.fz->df.store((int)std::max<size_t>(1, r.fz->members.size()));
+    auto t2 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < nq; i++) plan_finish(ix, plans[i]);
+    auto t3 = std::chrono::steady_clock::now();
+    WmResult wm; size_t sink = 0;
+    for (uint32_t i = 0; i < nq; i++) { const QueryPlan& P = plans[i]; if (P.blank || P.unsupported) continue; wm_collect(ix, P.searchText, true, wm); sink += wm.lists.size(); }
+    auto t4 = std::chrono::steady_clock::now();
+    infx_cov_query cq;
+    for (uint32_t i = 0; i < nq; i++) { const QueryPlan& P = plans[i]; if (P.blank || P.unsupported) continue; sink += (size_t)prepare_cov_query(ix, P.searchText, cq); }
+    auto t5 = std::chrono::steady_clock::now();
+    auto us = [&](auto a, auto b) { return std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3 / std::max<uint32_t>(1, nq); };
+    out_us[0] = us(t0, t1); out_us[1] = fc.ld1Ns.load() / 1e3 / std::max<uint32_t>(1, nq); out_us[2] = us(t2, t3); out_us[3] = us(t3, t4); out_us[4] = us(t4, t5) + (sink == (size_t)-1 ? 1 : 0);
+    return INFX_OK;
 }
 // WordMatcherLookup.Execute, fully enumerated (tests only): sorted unique ids
 int64_t infx_engine_wordmatcher(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int64_t cap) {

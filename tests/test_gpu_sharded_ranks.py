@@ -29,6 +29,13 @@ a, o = pack_texts(texts)
 batches = [(a, o), pack_texts(texts[:100]), pack_texts(texts[100:])]
 res = list(searcher.search_stream(batches, 20, 500))             # pipelined stream: planner thread + collectives in batch order
 single = searcher.search_packed(a, o, 20, 500)
+# sharded planning on (default: each rank runs the LD1 / WordMatcher host lookups for its half of the batch, blobs exchanged on the planning group)
+# and off (every rank plans the whole batch) must agree
+assert searcher.partition_planning and searcher.plan_group is not None
+off = ShardedSearcher(eng, TorchComm(dist), partition_planning=False)
+r_off = off.search_packed(a, o, 20, 500)
+for x, y in zip(single, r_off):
+    assert np.array_equal(x, y)
 if rank == 0:
     k, sc, t, c, f = res[0]
     np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f, k1=res[1][0], c1=res[1][3], k2=res[2][0], c2=res[2][3], ks=single[0], cs=single[3])

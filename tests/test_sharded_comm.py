@@ -64,3 +64,64 @@ def test_gloo_world2_collectives():
         pairs = [(float(sc[w, j, k]), int(ah0[w, j, k, 0])) for w in range(2) for k in range(int(ahc0[w, j]))]
         top = sorted(pairs, key=lambda x: (-x[0], x[1]))[:7]
         assert len(top) == 7 and all(top[i][0] >= top[i + 1][0] for i in range(6))
+
+
+def _prefetch_worker(rank, world, port, q):
+    """Sharded planning exchange on host-only engines (no GPU needed for the host lookups): each rank computes the LD1 expansions and the
+    WordMatcher descriptors of its half of the batch, the ranks all-gather the blobs on the planning group and import each other's."""
+    import ctypes as C
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from infidex_amd import SearchEngine
+    from infidex_amd.engine import _p
+    from infidex_amd.sharded import TorchComm
+    from tools.synth import Synth
+    s = Synth(4, docs=30000); arena, offs = s.docs()
+    e = SearchEngine.create_default(device=-1); e.index_flat(None, arena, offs, s.field_weights)
+    qa, qo = s.queries(200, qseed=5, fuzz=0.6)
+    nq = len(qo) - 1
+    sess = C.c_void_p(); assert e.L.infx_engine_default_session(e.h, C.byref(sess)) == 0
+    L = e.L; L.infx_session_prefetch_collect.restype = C.c_int64; L.infx_session_prefetch_pending.restype = C.c_int64
+
+    def collect(b, en):
+        n = L.infx_session_prefetch_collect(sess, nq, _p(qa, C.c_uint16), _p(qo, C.c_uint64), b, en, 500); assert n >= 8
+        blob = np.zeros(n, np.uint8); assert L.infx_session_prefetch_blob(sess, _p(blob, C.c_uint8), C.c_int64(n)) == 0
+        return blob
+    c = TorchComm(dist); g = c.planning_group()
+    begin, end = nq * rank // world, nq * (rank + 1) // world
+    mine = collect(begin, end)
+    blobs = c.allgather_bytes(mine, group=g)
+    assert np.array_equal(blobs[rank], mine)
+    for r, b in enumerate(blobs):
+        if r != rank:
+            assert L.infx_session_prefetch_import(sess, _p(np.ascontiguousarray(b), C.c_uint8), C.c_int64(b.size)) == 0
+    pending = int(L.infx_session_prefetch_pending(sess))
+    # a truncated blob is rejected, not half-imported silently
+    bad = np.ascontiguousarray(blobs[1 - rank][: max(9, blobs[1 - rank].size // 2)])
+    rc_bad = L.infx_session_prefetch_import(sess, _p(bad, C.c_uint8), C.c_int64(bad.size))
+    # the peer's slice, recomputed here after the import (LD1 expansions now come from the fuzzy cache): byte-identical to what the peer sent
+    ob, oe = nq * (1 - rank) // world, nq * (2 - rank) // world
+    again = collect(ob, oe)
+    q.put((rank, mine.tobytes(), blobs[1 - rank].tobytes(), again.tobytes(), pending, rc_bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_planning_exchange_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_prefetch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+    (_, mine0, peer0, again0, pend0, bad0), (_, mine1, peer1, again1, pend1, bad1) = got
+    assert peer0 == mine1 and peer1 == mine0                      # variable-length byte all-gather on the planning group
+    assert again0 == mine1 and again1 == mine0                    # same index + same text => same lookups, whoever computes them
+    assert pend0 > 0 and pend1 > 0                                # WordMatcher descriptor sets of the peer's queries wait for phase 0
+    assert bad0 != 0 and bad1 != 0
+    assert len(mine0) > 1000 and len(mine1) > 1000
