@@ -266,3 +266,18 @@ def test_random_synonym_maps_index_identically():
                 continue
             t, df, idf, mx = orc.last_terms()
             assert np.array_equal(p["term_ids"], t), (seed, q)
+
+
+def test_host_plan_profile_hook_reports_every_stage():
+    """infx_engine_host_plan_profile (measurement hook behind DESIGN.md section 6): runs the host planning stages of a batch single-threaded on a
+    host-only engine and reports microseconds per query; the LD1 share is part of plan_tokens."""
+    import ctypes as C
+    from infidex_amd import SearchEngine
+    from infidex_amd.engine import _p
+    from tools.synth import Synth
+    s = Synth(4, docs=20000); arena, offs = s.docs()
+    e = SearchEngine.create_default(device=-1); e.index_flat(None, arena, offs, s.field_weights)
+    qa, qo = s.queries(200, qseed=3, fuzz=0.5)
+    out = np.zeros(8, np.float64)
+    assert e.L.infx_engine_host_plan_profile(e.h, 200, _p(qa, C.c_uint16), _p(qo, C.c_uint64), 500, _p(out, C.c_double)) == 0
+    assert all(out[i] > 0 for i in (0, 2, 3, 4)) and 0 < out[1] <= out[0] and out[:5].sum() < 5000
