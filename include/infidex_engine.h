@@ -59,6 +59,8 @@ int32_t infx_engine_session_search_batch(infx_session* s, uint32_t nq, const uin
                                          int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                          uint32_t* out_counts, uint32_t* out_flags);
 int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, float* kernel_ms5, uint64_t* alg6);
+/* exact Stage-1 replay of the session's last batch: kernel milliseconds (part of kernel_ms5[1]) and the k_select flag reasons (infx_last_replay_stats) */
+int32_t infx_engine_session_last_replay(infx_session* s, float* ms, uint32_t* why3);
 
 /* Document-sharded operation: every rank indexes the whole corpus on the host (global df / avgdl / N), uploads
  * its contiguous doc range, and a batch runs as four phases with the collectives in between:

@@ -296,6 +296,10 @@ int32_t infx_last_alg_bytes(infx_stream* s, uint64_t* bytes);
 int32_t infx_last_candidates(infx_stream* s, uint64_t* n);
 /* Queries of the last batch whose Stage-1 cut was ambiguous and was replayed with the reference's sequential semantics (k_exact1). */
 int32_t infx_last_exact_replays(infx_stream* s, uint32_t* n);
+/* The replay of the last batch: duration of its kernels (ms, HIP events on the stream) and why k_select flagged the queries:
+ * why3[0] exact plateau (equal first-pass scores on both sides of the cut), [1] the best row left out lies inside the rounding band below the cut,
+ * [2] the best row left out was not gathered (flagged conservatively). */
+int32_t infx_last_replay_stats(infx_stream* s, float* ms, uint32_t* why3);
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,7 @@ struct infx_session {
     Batch* batch = nullptr;
     infx_stream* stream = nullptr;
     double tPrep1 = 0, tStage1 = 0, tPrep2 = 0, tStage2 = 0, tPost = 0;
-    float msAcc = 0, msSel = 0, msCov = 0, msPrep2 = 0, msFin = 0; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0; uint32_t exactReplays = 0;
+    float msAcc = 0, msSel = 0, msCov = 0, msPrep2 = 0, msFin = 0, msReplay = 0; uint32_t flagWhy[3] = {0, 0, 0}; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0; uint32_t exactReplays = 0;
     // last-batch introspection for parity tests
     std::vector<QueryPlan> lastPlans;
     std::vector<infx_hit> lastHits; std::vector<uint32_t> lastHitCount; int lastStride = 0;
@@ -75,6 +75,10 @@ struct CompiledFilter { infx_filter* dev = nullptr; uint32_t inFilter = 0; bool 
 struct infx_engine {
     // non-indexed document fields (DocumentFields) as dictionary-encoded columns + compiled Infiscript filters (config 5)
     std::vector<filt::Column> columns; std::mutex filterMu; std::unordered_map<std::string, CompiledFilter> filters;
+    std::vector<infx_filter*> retiredFilters;     // compiled against an older column set (a session's stream may still point at one): freed with the engine
+    // NumberOfDocumentsInFilter is cached per expression; a Filter parsed after a mutation counts again (the reference keeps the count on the Filter instance)
+    void invalidate_filter_counts() { std::lock_guard<std::mutex> lk(filterMu); for (auto& kv : filters) kv.second.counted = false; }
+    void retire_filters() { std::lock_guard<std::mutex> lk(filterMu); for (auto& kv : filters) if (kv.second.dev) retiredFilters.push_back(kv.second.dev); filters.clear(); }
     HostIndex ix;
     infx_engine_config cfg{};
     infx_index* dev = nullptr;
@@ -93,6 +97,13 @@ struct infx_engine {
 
 // byte-blob writer / reader of the sharded-planning exchange (infx_session_prefetch_*)
 namespace {
+// what a peer's descriptors index into: sizes of the host index (FNV-1a over the counts; every rank builds the same index from the same corpus)
+uint64_t index_fingerprint(const HostIndex& ix) {
+    const uint64_t v[6] = {(uint64_t)ix.N, (uint64_t)ix.terms.K(), (uint64_t)ix.terms.doc.size(), (uint64_t)ix.wmExact.doc.size(), (uint64_t)ix.wmLd1.doc.size(), (uint64_t)ix.text.size()};
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t x : v) for (int b = 0; b < 8; b++) { h ^= (x >> (8 * b)) & 0xFFu; h *= 1099511628211ull; }
+    return h;
+}
 struct BlobW { std::vector<uint8_t>& b; template <class T> void put(const T& v) { const uint8_t* p = (const uint8_t*)&v; b.insert(b.end(), p, p + sizeof(T)); }
                void bytes(const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; b.insert(b.end(), q, q + n); } };
 struct BlobR { const uint8_t* p; const uint8_t* e; bool ok = true;
@@ -130,6 +141,7 @@ void infx_engine_destroy(infx_engine* e) {
     if (S) delete S->batch;
     delete S;
     for (auto& kv : e->filters) if (kv.second.dev) infx_filter_destroy(kv.second.dev);
+    for (auto* f : e->retiredFilters) infx_filter_destroy(f);
     if (e->dev) infx_destroy(e->dev);
     delete e;
 }
@@ -657,7 +669,7 @@ static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, 
     float ms5[5] = {0, 0, 0, 0, 0}; infx_last_fused_timings(S->stream, ms5);
     S->msAcc = ms5[0]; S->msSel = ms5[1]; S->msPrep2 = ms5[2]; S->msCov = ms5[3]; S->msFin = ms5[4];
     uint64_t s1rows = 0; infx_last_fused_stats(S->stream, &s1rows, &S->s2Candidates, &S->s2TextBytes);
-    infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays);
+    infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays); infx_last_replay_stats(S->stream, &S->msReplay, S->flagWhy);
     {   // B_alg(q) = sum_t df_t * 5 B (4 B for fuzzy virtual terms) + card(C_q) * 4 B + depth * 12 B
         uint64_t ab = 0;
         for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
@@ -774,6 +786,7 @@ int64_t infx_session_prefetch_collect(infx_session* S, uint32_t nq, const uint16
         }
     });
     std::vector<uint8_t>& blob = S->prefetchBlob; blob.clear(); BlobW W{blob};
+    W.put<uint64_t>(index_fingerprint(ix));
     std::map<std::u16string, const FuzzyUnion*> words;          // ordered: the blob is a deterministic function of (index, slice)
     for (auto& P : plans) for (auto& r : P.rawTok) if (r.fz) words.emplace(r.text, r.fz.get());
     W.put<uint32_t>((uint32_t)words.size());
@@ -799,9 +812,10 @@ int32_t infx_session_prefetch_blob(infx_session* S, uint8_t* out, int64_t cap) {
     std::memcpy(out, S->prefetchBlob.data(), S->prefetchBlob.size()); return INFX_OK;
 }
 int32_t infx_session_prefetch_import(infx_session* S, const uint8_t* blob, int64_t len) {
-    if (!S || !blob || len < 8) return efail(INFX_EINVAL, "bad arguments");
+    if (!S || !blob || len < 16) return efail(INFX_EINVAL, "bad arguments");
     infx_engine* e = S->e; const HostIndex& ix = e->ix;
     BlobR R{blob, blob + len};
+    if (R.get<uint64_t>() != index_fingerprint(ix)) return efail(INFX_EINVAL, "prefetch blob comes from a different index (ranks must index the same corpus with the same build)");
     const uint32_t nw = R.get<uint32_t>();
     for (uint32_t k = 0; k < nw && R.ok; k++) {
         const uint16_t wl = R.get<uint16_t>(); const uint8_t* wp = R.take((size_t)wl * 2);
@@ -823,6 +837,11 @@ int32_t infx_session_prefetch_import(infx_session* S, const uint8_t* blob, int64
         const uint32_t no = R.get<uint32_t>(); const uint8_t* op = R.take((size_t)no * 4);
         if (!R.ok) break;
         pre.owned.resize(no); if (no) std::memcpy(pre.owned.data(), op, (size_t)no * 4);
+        for (auto& L : pre.lists) {          // descriptors go straight to the device: reject anything outside the arrays they index
+            const uint64_t lim = L.src == 0 ? ix.wmExact.doc.size() : (L.src == 1 ? ix.wmLd1.doc.size() : (L.src == 2 ? (uint64_t)no : 0));
+            if (L.src > 2 || L.off > lim || (uint64_t)L.len > lim - L.off) return efail(INFX_EINVAL, "prefetch blob: WordMatcher descriptor out of range");
+        }
+        for (int32_t id : pre.owned) if (id < 0 || id >= ix.N) return efail(INFX_EINVAL, "prefetch blob: affix document id out of range");
         std::u16string text((size_t)tl, u'\0'); std::memcpy(&text[0], tp, (size_t)tl * 2);
         S->wmPre.emplace(std::move(text), std::move(pre));
     }
@@ -875,7 +894,7 @@ int32_t infx_session_phase2(infx_session* S, const uint32_t* global_counts, infx
         int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, S->lastHits.data(), S->lastHitCount.data());
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
-        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays);
+        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays); infx_last_replay_stats(S->stream, &S->msReplay, S->flagWhy);
         uint64_t ab = 0, nh = 0;
         for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)S->e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
         for (uint32_t c : S->lastHitCount) nh += c;
@@ -920,7 +939,7 @@ int32_t infx_session_phase2x(infx_session* S, const uint32_t* global_counts, voi
         int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, (infx_hit*)hits, (uint32_t*)hitcounts);
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
-        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays);
+        infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays); infx_last_replay_stats(S->stream, &S->msReplay, S->flagWhy);
         uint64_t ab = 0;
         for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)S->e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
         S->algBytes = ab + S->s1Candidates * 4ull + (uint64_t)B.nd * B.depth * 12ull;
@@ -971,6 +990,12 @@ int32_t infx_engine_session_last_timings(infx_session* S, double* host_ms5, floa
     if (host_ms5) { host_ms5[0] = S->tPrep1; host_ms5[1] = S->tStage1; host_ms5[2] = S->tPrep2; host_ms5[3] = S->tStage2; host_ms5[4] = S->tPost; }
     if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; kernel_ms3[3] = S->msPrep2; kernel_ms3[4] = S->msFin; }
     if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; alg_bytes3[5] = S->exactReplays; }
+    return INFX_OK;
+}
+
+int32_t infx_engine_session_last_replay(infx_session* S, float* ms, uint32_t* why3) {
+    if (!S) return efail(INFX_EINVAL, "null");
+    if (ms) *ms = S->msReplay; if (why3) { why3[0] = S->flagWhy[0]; why3[1] = S->flagWhy[1]; why3[2] = S->flagWhy[2]; }
     return INFX_OK;
 }
 
@@ -1135,6 +1160,7 @@ int32_t infx_engine_delete_documents(infx_engine* e, const int64_t* keys, int64_
     }
     if (out_marked) *out_marked = marked;
     if (e->dev) { int32_t rc = infx_set_deleted(e->dev, (uint32_t)N, e->deleted.data()); if (rc) { g_eerr = infx_last_error(); return rc; } }
+    e->invalidate_filter_counts();
     return INFX_OK;
 }
 // Clears every Deleted flag (what a reload of the undeleted documents would give).
@@ -1142,6 +1168,7 @@ int32_t infx_engine_restore_documents(infx_engine* e) {
     if (!e) return efail(INFX_EINVAL, "null argument");
     e->deleted.clear();
     if (e->dev && e->indexed) { int32_t rc = infx_set_deleted(e->dev, 0, nullptr); if (rc) { g_eerr = infx_last_error(); return rc; } }
+    e->invalidate_filter_counts();
     return INFX_OK;
 }
 
@@ -1163,6 +1190,7 @@ int32_t infx_engine_add_column(infx_engine* e, const char* name, int32_t kind, i
         if (rc) { g_eerr = infx_last_error(); return rc; }
     }
     e->columns.push_back(std::move(c));
+    e->retire_filters();      // leaf tables of filters compiled before this field existed treat it as null: compile again on next use
     return INFX_OK;
 }
 int32_t infx_engine_column_count(infx_engine* e) { return e ? (int32_t)e->columns.size() : 0; }

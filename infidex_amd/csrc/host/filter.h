@@ -48,7 +48,7 @@ inline std::string fmt_double(double x) {          // System.Double.ToString(): 
     return neg ? "-" + r : r;
 }
 inline std::string text_of(const Boxed& v) { return v.kind == 1 ? std::to_string(v.i) : v.kind == 2 ? fmt_double(v.d) : v.kind == 3 ? v.s : std::string(); }
-inline bool as_number(const std::string& t, double& out) {        // double.TryParse, invariant culture, plain / exponent forms
+inline bool as_number(const std::string& t, double& out) {        // double.TryParse: NumberStyles.Float | AllowThousands, invariant culture
     size_t a = 0, b = t.size();
     while (a < b && isspace((unsigned char)t[a])) a++;
     while (b > a && isspace((unsigned char)t[b - 1])) b--;
@@ -57,17 +57,58 @@ inline bool as_number(const std::string& t, double& out) {        // double.TryP
     if (s == "NaN") { out = NAN; return true; }
     if (s == "Infinity" || s == "+Infinity") { out = INFINITY; return true; }
     if (s == "-Infinity") { out = -INFINITY; return true; }
-    for (unsigned char c : s) if (!(isdigit(c) || c == '.' || c == '+' || c == '-' || c == 'e' || c == 'E')) return false;
-    char* end = nullptr; out = strtod(s.c_str(), &end);
-    return end != s.c_str() && *end == 0;
+    std::string plain; plain.reserve(s.size());
+    bool sawDigit = false, mantissaInt = true;            // group separators are legal only among the integer digits ("1,000", "12,34.5")
+    for (unsigned char c : s) {
+        if (isdigit(c)) { sawDigit = true; plain.push_back((char)c); continue; }
+        if (c == ',') { if (mantissaInt && sawDigit) continue; return false; }
+        if (c == '.' || c == 'e' || c == 'E') { mantissaInt = false; plain.push_back((char)c); continue; }
+        if (c == '+' || c == '-') { plain.push_back((char)c); continue; }
+        return false;
+    }
+    char* end = nullptr; out = strtod(plain.c_str(), &end);
+    return end != plain.c_str() && *end == 0;
 }
-inline unsigned char fold(unsigned char c) { return (c >= 'a' && c <= 'z') ? (unsigned char)(c - 32) : c; }
+// OrdinalIgnoreCase (and RegexOptions.IgnoreCase for LIKE): .NET upper-cases each UTF-16 code unit with the invariant simple mapping and compares the
+// units.  Case pairs are described as runs: {first lower, last lower, stride, delta to upper}; U+0131 / U+017F are left alone as in the BCL's ordinal
+// casing.  Covers Latin (incl. the Czech school corpus), Greek, Cyrillic, Armenian, Latin Extended Additional.
+struct CaseRun { uint16_t lo, hi, step; int32_t delta; };
+inline uint16_t fold_unit(uint16_t c) {
+    static const CaseRun runs[] = {
+        {0x0061, 0x007A, 1, -32}, {0x00B5, 0x00B5, 1, 0x39C - 0xB5}, {0x00E0, 0x00F6, 1, -32}, {0x00F8, 0x00FE, 1, -32}, {0x00FF, 0x00FF, 1, 0x178 - 0xFF},
+        {0x0101, 0x012F, 2, -1}, {0x0133, 0x0137, 2, -1}, {0x013A, 0x0148, 2, -1}, {0x014B, 0x0177, 2, -1}, {0x017A, 0x017E, 2, -1},
+        {0x01CE, 0x01DC, 2, -1}, {0x01DF, 0x01EF, 2, -1}, {0x01F9, 0x021F, 2, -1}, {0x0223, 0x0233, 2, -1}, {0x0247, 0x024F, 2, -1},
+        {0x03AC, 0x03AC, 1, 0x386 - 0x3AC}, {0x03AD, 0x03AF, 1, -0x25}, {0x03B1, 0x03C1, 1, -32}, {0x03C2, 0x03C2, 1, 0x3A3 - 0x3C2}, {0x03C3, 0x03CB, 1, -32},
+        {0x03CC, 0x03CC, 1, 0x38C - 0x3CC}, {0x03CD, 0x03CE, 1, -0x3F},
+        {0x0430, 0x044F, 1, -32}, {0x0450, 0x045F, 1, -80}, {0x0461, 0x0481, 2, -1}, {0x048B, 0x04BF, 2, -1}, {0x04C2, 0x04CE, 2, -1}, {0x04CF, 0x04CF, 1, 0x4C0 - 0x4CF},
+        {0x04D1, 0x052F, 2, -1}, {0x0561, 0x0586, 1, -48}, {0x1E01, 0x1E95, 2, -1}, {0x1EA1, 0x1EFF, 2, -1},
+    };
+    for (const CaseRun& r : runs) if (c >= r.lo && c <= r.hi && (c - r.lo) % r.step == 0) return (uint16_t)(c + r.delta);
+    return c;
+}
+inline std::u16string folded(const std::string& s) {               // UTF-8 -> folded UTF-16 units
+    std::u16string o; o.reserve(s.size());
+    size_t i = 0; const size_t n = s.size();
+    while (i < n) {
+        const unsigned char c = (unsigned char)s[i];
+        uint32_t cp; size_t len;
+        if (c < 0x80 || c < 0xC0) { cp = c; len = 1; }
+        else if (c < 0xE0) { cp = c & 0x1Fu; len = 2; }
+        else if (c < 0xF0) { cp = c & 0x0Fu; len = 3; }
+        else { cp = c & 0x07u; len = 4; }
+        if (i + len > n) { cp = c; len = 1; }
+        for (size_t k = 1; k < len; k++) cp = (cp << 6) | ((unsigned char)s[i + k] & 0x3Fu);
+        i += len;
+        if (cp > 0xFFFF) { cp -= 0x10000; o.push_back((char16_t)(0xD800 | (cp >> 10))); o.push_back((char16_t)(0xDC00 | (cp & 0x3FF))); }
+        else o.push_back((char16_t)fold_unit((uint16_t)cp));
+    }
+    return o;
+}
 inline int icmp(const std::string& a, const std::string& b) {     // StringComparison.OrdinalIgnoreCase
-    const size_t n = std::min(a.size(), b.size());
-    for (size_t k = 0; k < n; k++) { const unsigned char x = fold((unsigned char)a[k]), y = fold((unsigned char)b[k]); if (x != y) return x < y ? -1 : 1; }
-    return a.size() == b.size() ? 0 : (a.size() < b.size() ? -1 : 1);
+    const std::u16string x = folded(a), y = folded(b);
+    return x < y ? -1 : (y < x ? 1 : 0);                           // char16_t compares as unsigned code units
 }
-inline std::string upper(std::string s) { for (auto& c : s) c = (char)fold((unsigned char)c); return s; }
+inline std::string upper(std::string s) { for (auto& c : s) if (c >= 'a' && c <= 'z') c = (char)(c - 32); return s; }     // ASCII: keywords of the expression language
 // value <op> constant with the VM's coercions; `isnull`: the document has no such field / a null value
 inline bool same(bool isnull, const std::string& v, const std::string& c) { return !isnull && icmp(v, c) == 0; }          // constants are never null
 inline int order(bool isnull, const std::string& v, const std::string& c) {
@@ -76,15 +117,16 @@ inline int order(bool isnull, const std::string& v, const std::string& c) {
     if (as_number(v, x) && as_number(c, y)) return x < y ? -1 : (x > y ? 1 : (x == y ? 0 : (std::isnan(x) ? (std::isnan(y) ? 0 : -1) : 1)));
     return icmp(v, c);
 }
-inline bool wildcard(const std::string& text, const std::string& pat) {     // LIKE: % any run, _ any one character (not a newline), whole string, ignore case
+inline bool wildcard(const std::string& text0, const std::string& pat0) {     // LIKE: % any run, _ any one UTF-16 unit (not a newline), whole string, ignore case
+    const std::u16string text = folded(text0), pat = folded(pat0);
     const size_t n = text.size(), m = pat.size();
     std::vector<char> prev(m + 1, 0), cur(m + 1, 0);
-    prev[0] = 1; for (size_t j = 1; j <= m; j++) prev[j] = prev[j - 1] && pat[j - 1] == '%';
+    prev[0] = 1; for (size_t j = 1; j <= m; j++) prev[j] = prev[j - 1] && pat[j - 1] == u'%';
     for (size_t i = 1; i <= n; i++) {
         cur[0] = 0;
         for (size_t j = 1; j <= m; j++) {
-            const char p = pat[j - 1]; const bool nl = text[i - 1] == '\n';
-            cur[j] = p == '%' ? (cur[j - 1] || (prev[j] && !nl)) : p == '_' ? (prev[j - 1] && !nl) : (prev[j - 1] && fold((unsigned char)p) == fold((unsigned char)text[i - 1]));
+            const char16_t p = pat[j - 1]; const bool nl = text[i - 1] == u'\n';
+            cur[j] = p == u'%' ? (cur[j - 1] || (prev[j] && !nl)) : p == u'_' ? (prev[j - 1] && !nl) : (prev[j - 1] && p == text[i - 1]);
         }
         prev.swap(cur);
     }
@@ -109,9 +151,9 @@ inline bool leaf_holds(const Leaf& L, const Boxed& v) {
         case L_LE: return order(isnull, t, L.consts[0]) <= 0;
         case L_BETWEEN: return order(isnull, t, L.consts[0]) >= 0 && order(isnull, t, L.consts[1]) <= 0;
         case L_IN: for (auto& c : L.consts) if (same(isnull, t, c)) return true; return false;
-        case L_CONTAINS: return upper(t).find(upper(L.consts[0])) != std::string::npos;
-        case L_STARTS: { const std::string a = upper(t), b = upper(L.consts[0]); return a.size() >= b.size() && a.compare(0, b.size(), b) == 0; }
-        case L_ENDS: { const std::string a = upper(t), b = upper(L.consts[0]); return a.size() >= b.size() && a.compare(a.size() - b.size(), b.size(), b) == 0; }
+        case L_CONTAINS: return folded(t).find(folded(L.consts[0])) != std::u16string::npos;
+        case L_STARTS: { const std::u16string a = folded(t), b = folded(L.consts[0]); return a.size() >= b.size() && a.compare(0, b.size(), b) == 0; }
+        case L_ENDS: { const std::u16string a = folded(t), b = folded(L.consts[0]); return a.size() >= b.size() && a.compare(a.size() - b.size(), b.size(), b) == 0; }
         case L_LIKE: return wildcard(t, L.consts[0]);
         case L_ISNULL: return isnull || (v.kind == 3 && v.s.empty());
         case L_NOTNULL: return !(isnull || (v.kind == 3 && v.s.empty()));

@@ -67,7 +67,7 @@ struct infx_index {
     std::vector<int32_t> hDf;
     std::vector<uint32_t> hSkipIdx;   // host copy of DevIndex::skipIdx (filled by infx_upload_postings)
     uint8_t* dDeleted = nullptr;      // device copy of the global Document.Deleted flags (infx_set_deleted)
-    const uint32_t* colCodes[FILT_MAXCOL] = {}; uint32_t colValues[FILT_MAXCOL] = {}; uint32_t colDocs[FILT_MAXCOL] = {};   // device-resident columns (infx_upload_column)
+    const uint32_t* colCodes[FILT_MAXCOL] = {}; uint32_t colValues[FILT_MAXCOL] = {}; uint32_t colDocs[FILT_MAXCOL] = {}; uint32_t colCap[FILT_MAXCOL] = {};   // device-resident columns (infx_upload_column)
     std::vector<uint64_t> hPsOff;
     int rank = 0, nranks = 1;
 };
@@ -223,7 +223,8 @@ struct infx_stream {
     size_t capFDocs = 0, capFacCodes = 0, capFacCounts = 0, capFacN = 0;
     std::vector<uint32_t> hFacCodes, hFacCounts, hFacN; uint32_t facetNq = 0;
     hipStream_t st = nullptr;
-    hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1, evSync;
+    hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1, evX0, evX1, evSync;
+    bool timedReplay = false; float msReplay = 0.f; uint32_t lastFlagWhy[4] = {0, 0, 0, 0};     // exact replay of the last batch: kernel time, why its queries were flagged
     // fused pipeline workspaces
     void *dFQ = nullptr, *dFLists = nullptr, *dFOwned = nullptr, *dFS1 = nullptr, *dFMeta = nullptr, *dFQueries = nullptr, *dFKeys = nullptr, *dFScores = nullptr, *dFTies = nullptr, *dFCounts = nullptr, *dFFlags = nullptr, *dFErr = nullptr, *dFHitsAll = nullptr, *dFHcAll = nullptr, *dFPairs = nullptr;
     size_t capFQ = 0, capFLists = 0, capFOwned = 0, capFS1 = 0, capFMeta = 0, capFQueries = 0, capFKeys = 0, capFScores = 0, capFTies = 0, capFCounts = 0, capFFlags = 0, capFErr = 0, capFHitsAll = 0, capFHcAll = 0, capFPairs = 0;
@@ -420,6 +421,7 @@ static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
       if (lds1 > attr1) { HIPCHK(hipFuncSetAttribute((const void*)k_exact1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); attr1 = lds1; } }
     Arena ar = make_arena(s);
     HIPCHK(hipMemsetAsync(s->dExactStat, 0, 16, s->st));
+    HIPCHK(hipEventRecord(s->evX0, s->st));
     const bool fast = !slowOnly && depthCap <= EXS_MAXDEPTH;
     if (fast) {
         // chunk table: every query needs at most (containers + reserved rows / 4096 + 2) entries
@@ -446,7 +448,9 @@ static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
     k_exact1<<<nq, EX_THREADS, lds1, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag,
                                              fast ? 2u : 1u, ix->avgdl, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, depthCap, s->dExactStat);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->evX1, s->st)); s->timedReplay = true;
     DOWN(s->lastExact2, s->dExactStat, 8);          // [0] replayed queries, [1] of them through the sequential k_exact1 fallback; lands at the caller's synchronisation
+    DOWN(s->lastFlagWhy, s->dExactStat + 4, 16);
     return INFX_OK;
 }
 
@@ -632,12 +636,12 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     HIPCHK(hipSetDevice(ix->cfg.device));
     infx_stream* s = new infx_stream(); s->ix = ix;
     HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-    hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1, &s->evP0, &s->evP1, &s->evF0, &s->evF1};
+    hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1, &s->evP0, &s->evP1, &s->evF0, &s->evF1, &s->evX0, &s->evX1};
     for (auto e : ev) HIPCHK(hipEventCreate(e));
     HIPCHK(hipEventCreateWithFlags(&s->evSync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
     HIPCHK(hipMalloc((void**)&s->dStats, 64)); HIPCHK(hipMemset(s->dStats, 0, 64));
-    HIPCHK(hipMalloc((void**)&s->dExactStat, 16)); HIPCHK(hipMemset(s->dExactStat, 0, 16));
+    HIPCHK(hipMalloc((void**)&s->dExactStat, 32)); HIPCHK(hipMemset(s->dExactStat, 0, 32));      // [0..3] replay outcome counters, [4..7] k_select flag reasons
     HIPCHK(hipMalloc((void**)&s->exCounters, 16)); HIPCHK(hipMemset(s->exCounters, 0, 16));
     *out = s; return INFX_OK;
 }
@@ -650,7 +654,7 @@ void infx_stream_destroy(infx_stream* s) {
     for (void* p : ps) if (p) hipFree(p);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
-    hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1, s->evP0, s->evP1, s->evF0, s->evF1};
+    hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1, s->evP0, s->evP1, s->evF0, s->evF1, s->evX0, s->evX1};
     for (auto e : ev) hipEventDestroy(e);
     hipEventDestroy(s->evSync);
     if (s->st) hipStreamDestroy(s->st);
@@ -785,7 +789,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evA1, s->st));
     s->timedAcc = true;
-    s->lastQ.assign(q, q + nq); s->lastNq = nq; s->lastExact2[0] = s->lastExact2[1] = 0;
+    s->lastQ.assign(q, q + nq); s->lastNq = nq; s->lastExact2[0] = s->lastExact2[1] = 0; s->msReplay = 0.f; s->timedReplay = false; s->lastFlagWhy[0] = s->lastFlagWhy[1] = s->lastFlagWhy[2] = 0;
     return INFX_OK;
 }
 
@@ -827,7 +831,8 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     Arena ar = make_arena(s);
     HIPCHK(hipEventRecord(s->evS0, s->st));
     const bool exact = exact_possible(s);
-    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr);
+    if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
+    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr);
     if (exact) { int32_t rc_ = enqueue_exact(s, nq, maxDepth); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evS1, s->st));
@@ -930,7 +935,8 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth) 
     if (nd) {
         k_rules<<<(nd + 255) / 256, 256, 0, s->st>>>((const infx_query*)s->dFQueries, (const uint32_t*)s->dCounts, (SelRule*)s->dRules, nd);
         const bool exact = exact_possible(s);
-        k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr);
+        if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
+        k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr);
         if (exact) { int32_t rc_ = enqueue_exact(s, nd, depth); if (rc_) return rc_; }
     }
     HIPCHK(hipGetLastError());
@@ -1240,6 +1246,13 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     HIPCHK(hipGetLastError());
     return INFX_OK;     // the write pass stays queued on the stream; infx_stage1_accumulate is ordered behind it
 }
+int32_t infx_last_replay_stats(infx_stream* s, float* ms, uint32_t* why3) {
+    if (!s) return fail(INFX_EINVAL, "null argument%s");
+    if (s->timedReplay) { hipEventElapsedTime(&s->msReplay, s->evX0, s->evX1); s->timedReplay = false; }
+    if (ms) *ms = s->msReplay;
+    if (why3) { why3[0] = s->lastFlagWhy[0]; why3[1] = s->lastFlagWhy[1]; why3[2] = s->lastFlagWhy[2]; }
+    return INFX_OK;
+}
 int32_t infx_last_exact_replays(infx_stream* s, uint32_t* n) {
     if (!s || !n) return fail(INFX_EINVAL, "null argument%s");
     *n = s->lastExact2[0] + s->lastExact2[1]; return INFX_OK;
@@ -1258,8 +1271,10 @@ int32_t infx_last_alg_bytes(infx_stream* s, uint64_t* bytes) {
 int32_t infx_upload_column(infx_index* ix, uint32_t col, uint32_t total_docs, const uint32_t* codes, uint32_t num_values) {
     if (!ix || col >= FILT_MAXCOL || (total_docs && !codes)) return fail(INFX_EINVAL, "bad column arguments%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
-    uint32_t* d = nullptr;
-    HIPCHK(dalloc(ix, &d, (size_t)total_docs + 1));
+    if (ix->haveDocs && (uint64_t)total_docs < (uint64_t)ix->d.docBase + (uint64_t)ix->d.N) return fail(INFX_EINVAL, "a column needs one code per GLOBAL internal id covering this shard%s");
+    HIPCHK(hipDeviceSynchronize());                      // exclusive call (the reference's write lock): no search is in flight
+    uint32_t* d = const_cast<uint32_t*>(ix->colCodes[col]);
+    if (!d || ix->colCap[col] < total_docs) { HIPCHK(dalloc(ix, &d, (size_t)total_docs + 1)); ix->colCap[col] = total_docs; }     // a re-upload reuses the column's buffer
     if (total_docs) HIPCHK(hipMemcpy(d, codes, (size_t)total_docs * 4, hipMemcpyHostToDevice));
     ix->colCodes[col] = d; ix->colValues[col] = num_values; ix->colDocs[col] = total_docs;
     return INFX_OK;
@@ -1308,11 +1323,12 @@ int32_t infx_filter_count(infx_stream* s, infx_filter* f, uint32_t* count) {
     if (!ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
-    for (uint32_t l = 0; l < f->nleaves; l++) { /* columns are indexed by GLOBAL internal id: they must cover this shard */ }
+    for (int c = 0; c < FILT_MAXCOL; c++)       // columns are indexed by GLOBAL internal id: every uploaded column must cover this shard
+        if (ix->colCodes[c] && (uint64_t)ix->colDocs[c] < (uint64_t)ix->d.docBase + (uint64_t)ix->d.N) return fail(INFX_EINVAL, "a column holds fewer rows than this shard's documents%s");
     HIPCHK(hipMemsetAsync(s->dExactStat, 0, 4, s->st));
     DevColumns cols; for (int c = 0; c < FILT_MAXCOL; c++) cols.codes[c] = ix->colCodes[c];
     const int n = ix->d.N;
-    if (n > 0) k_filter_count<<<std::min(4096, (n + 255) / 256), 256, 0, s->st>>>(f->d, cols, ix->d.docBase, n, s->dExactStat);
+    if (n > 0) k_filter_count<<<std::min(4096, (n + 255) / 256), 256, 0, s->st>>>(f->d, cols, ix->d.docBase, n, ix->d.deleted, s->dExactStat);
     HIPCHK(hipGetLastError());
     DOWN(count, s->dExactStat, 4);
     SYNC();
@@ -1321,6 +1337,8 @@ int32_t infx_filter_count(infx_stream* s, infx_filter* f, uint32_t* count) {
 int32_t infx_stream_set_postfilter(infx_stream* s, infx_filter* f, uint32_t nfacet, const uint32_t* facet_cols) {
     if (!s || nfacet > INFX_MAX_FACET_COLS || (nfacet && !facet_cols) || (f && f->ix != s->ix)) return fail(INFX_EINVAL, "bad post-filter arguments%s");
     for (uint32_t c = 0; c < nfacet; c++) if (facet_cols[c] >= FILT_MAXCOL || !s->ix->colCodes[facet_cols[c]]) return fail(INFX_EINVAL, "facet column was not uploaded%s");
+    for (int c = 0; c < FILT_MAXCOL; c++)       // rows carry GLOBAL internal ids: a column shorter than the corpus would be read out of bounds
+        if (s->ix->colCodes[c] && s->ix->colDocs[c] < (uint32_t)s->ix->d.totalDocs) return fail(INFX_EINVAL, "a column holds fewer rows than the corpus has documents%s");
     s->postFilter = f; s->nFacet = nfacet;
     for (uint32_t c = 0; c < INFX_MAX_FACET_COLS; c++) s->facetCols[c] = c < nfacet ? facet_cols[c] : 0;
     return INFX_OK;

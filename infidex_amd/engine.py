@@ -387,7 +387,10 @@ class Session:
     def last_timings(self):
         host = np.zeros(5, np.float64); kern = np.zeros(5, np.float32); alg = np.zeros(6, np.uint64)
         self.engine._check(self.L.infx_engine_session_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))
-        return {"plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
+        rms = C.c_float(0); why = np.zeros(3, np.uint32)
+        self.engine._check(self.L.infx_engine_session_last_replay(self.h, C.byref(rms), _p(why, C.c_uint32)))
+        return {"k_replay_ms": float(rms.value), "flag_plateau": int(why[0]), "flag_band": int(why[1]), "flag_unknown": int(why[2]),
+                "plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
                 "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
                 "k_prep2_ms": float(kern[3]), "k_finalize_ms": float(kern[4]),
                 "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2]),

@@ -73,25 +73,74 @@ inline std::string to_string(const Value& v) {      // object.ToString()
         default: return "";
     }
 }
-inline bool try_parse_double(const std::string& s0, double& out) {
+inline bool try_parse_double(const std::string& s0, double& out) {      // double.TryParse(string): NumberStyles.Float | AllowThousands, invariant culture
     size_t a = 0, b = s0.size();
     while (a < b && isspace((unsigned char)s0[a])) a++;
     while (b > a && isspace((unsigned char)s0[b - 1])) b--;
     if (a == b) return false;
     std::string s = s0.substr(a, b - a);
-    for (char c : s) if (!(isdigit((unsigned char)c) || c == '+' || c == '-' || c == '.' || c == 'e' || c == 'E')) {
-        if (s == "Infinity" || s == "+Infinity") { out = INFINITY; return true; }
-        if (s == "-Infinity") { out = -INFINITY; return true; }
-        if (s == "NaN") { out = NAN; return true; }
-        return false;
+    if (s == "Infinity" || s == "+Infinity") { out = INFINITY; return true; }
+    if (s == "-Infinity") { out = -INFINITY; return true; }
+    if (s == "NaN") { out = NAN; return true; }
+    // AllowThousands: ',' is accepted inside the integer part once a digit has been read (group sizes are not checked by the BCL parser)
+    std::string t; bool digitSeen = false, intPart = true;
+    for (char c : s) {
+        if (isdigit((unsigned char)c)) { digitSeen = true; t.push_back(c); }
+        else if (c == ',' && intPart && digitSeen) continue;
+        else if (c == '.' || c == 'e' || c == 'E') { intPart = false; t.push_back(c); }
+        else if (c == '+' || c == '-') t.push_back(c);
+        else return false;
     }
-    char* end = nullptr; out = strtod(s.c_str(), &end);
-    return end && *end == 0 && end != s.c_str();
+    char* end = nullptr; out = strtod(t.c_str(), &end);
+    return end && *end == 0 && end != t.c_str();
 }
-inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }     // OrdinalIgnoreCase on the ASCII range the tests use (UTF-8 bytes above it compare as is)
-inline int cmp_oic(const std::string& a, const std::string& b) {
+// StringComparison.OrdinalIgnoreCase / RegexOptions.IgnoreCase: both sides are upper-cased per UTF-16 code unit with the invariant SIMPLE case mapping
+// and compared ordinally.  Restated for the scripts the corpora use (Basic Latin, Latin-1, Latin Extended-A/B pairs, Greek, Cyrillic, Armenian);
+// U+0131 and U+017F keep their value (the BCL's ordinal casing does not fold them onto ASCII I / S).  Strings here are UTF-8.
+inline uint32_t up_cp(uint32_t c) {
+    if (c < 0x80) return (c >= 'a' && c <= 'z') ? c - 32 : c;
+    if (c == 0xB5) return 0x39C;
+    if (c >= 0xE0 && c <= 0xFE && c != 0xF7) return c - 0x20;
+    if (c == 0xFF) return 0x178;
+    if (c >= 0x100 && c <= 0x17F) {
+        if (c == 0x131 || c == 0x138 || c == 0x149 || c == 0x17F) return c;
+        if ((c >= 0x139 && c <= 0x148) || (c >= 0x179 && c <= 0x17E)) return (c & 1) ? c : c - 1;      // upper = odd code point
+        return (c & 1) ? c - 1 : c;                                                                   // upper = even code point
+    }
+    if (c >= 0x180 && c <= 0x24F) {
+        if ((c >= 0x1CD && c <= 0x1DC)) return (c & 1) ? c : c - 1;
+        if ((c >= 0x1DE && c <= 0x1EF) || (c >= 0x1F8 && c <= 0x21F) || (c >= 0x222 && c <= 0x233) || (c >= 0x246 && c <= 0x24F)) return (c & 1) ? c - 1 : c;
+        return c;
+    }
+    if (c == 0x3AC) return 0x386; if (c >= 0x3AD && c <= 0x3AF) return c - 0x25; if (c == 0x3CC) return 0x38C; if (c == 0x3CD || c == 0x3CE) return c - 0x3F;
+    if (c == 0x3C2) return 0x3A3;
+    if (c >= 0x3B1 && c <= 0x3CB) return c - 0x20;
+    if (c >= 0x430 && c <= 0x44F) return c - 0x20;
+    if (c >= 0x450 && c <= 0x45F) return c - 0x50;
+    if ((c >= 0x460 && c <= 0x481) || (c >= 0x48A && c <= 0x4BF) || (c >= 0x4D0 && c <= 0x52F)) return (c & 1) ? c - 1 : c;
+    if (c >= 0x4C1 && c <= 0x4CE) return (c & 1) ? c : c - 1;
+    if (c == 0x4CF) return 0x4C0;
+    if (c >= 0x561 && c <= 0x586) return c - 0x30;
+    if (c >= 0x1E00 && c <= 0x1EFF) { if (c >= 0x1E96 && c <= 0x1E9F) return c; return (c & 1) ? c - 1 : c; }
+    return c;
+}
+inline std::vector<uint16_t> up_units(const std::string& s) {       // UTF-8 -> upper-cased UTF-16 code units (invalid bytes pass through as single units)
+    std::vector<uint16_t> o; o.reserve(s.size());
+    for (size_t i = 0; i < s.size();) {
+        unsigned char c = (unsigned char)s[i]; uint32_t cp = c; int n = 1;
+        if (c >= 0xF0 && i + 3 < s.size()) { cp = ((c & 7u) << 18) | (((unsigned char)s[i + 1] & 0x3Fu) << 12) | (((unsigned char)s[i + 2] & 0x3Fu) << 6) | ((unsigned char)s[i + 3] & 0x3Fu); n = 4; }
+        else if (c >= 0xE0 && c < 0xF0 && i + 2 < s.size()) { cp = ((c & 0xFu) << 12) | (((unsigned char)s[i + 1] & 0x3Fu) << 6) | ((unsigned char)s[i + 2] & 0x3Fu); n = 3; }
+        else if (c >= 0xC0 && c < 0xE0 && i + 1 < s.size()) { cp = ((c & 0x1Fu) << 6) | ((unsigned char)s[i + 1] & 0x3Fu); n = 2; }
+        i += (size_t)n;
+        if (cp >= 0x10000) { cp -= 0x10000; o.push_back((uint16_t)(0xD800 + (cp >> 10))); o.push_back((uint16_t)(0xDC00 + (cp & 0x3FF))); }
+        else o.push_back((uint16_t)up_cp(cp));
+    }
+    return o;
+}
+inline int cmp_oic(const std::string& a0, const std::string& b0) {
+    const std::vector<uint16_t> a = up_units(a0), b = up_units(b0);
     size_t n = std::min(a.size(), b.size());
-    for (size_t i = 0; i < n; i++) { unsigned char x = (unsigned char)up(a[i]), y = (unsigned char)up(b[i]); if (x != y) return x < y ? -1 : 1; }
+    for (size_t i = 0; i < n; i++) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
     return a.size() < b.size() ? -1 : (a.size() > b.size() ? 1 : 0);
 }
 inline bool are_equal(const Value* l, const Value* r) {          // FilterVM.AreEqual :329-338
@@ -108,16 +157,17 @@ inline int compare_to(const Value* l, const Value* r) {           // FilterVM.Co
     if (try_parse_double(ls, a) && try_parse_double(rs, b)) return a < b ? -1 : (a > b ? 1 : (a == b ? 0 : (std::isnan(a) ? (std::isnan(b) ? 0 : -1) : 1)));
     return cmp_oic(ls, rs);
 }
-inline bool like_match(const std::string& text, const std::string& pat) {      // ^escape(pat) with % -> .*, _ -> . $, IgnoreCase
+inline bool like_match(const std::string& text0, const std::string& pat0) {      // ^escape(pat) with % -> .*, _ -> . $, IgnoreCase; '.' = one UTF-16 unit
+    const std::vector<uint16_t> text = up_units(text0), pat = up_units(pat0);
     size_t n = text.size(), m = pat.size();
     std::vector<std::vector<char>> dp(n + 1, std::vector<char>(m + 1, 0));
     dp[0][0] = 1;
     for (size_t j = 1; j <= m; j++) dp[0][j] = dp[0][j - 1] && pat[j - 1] == '%';
     for (size_t i = 1; i <= n; i++) for (size_t j = 1; j <= m; j++) {
-        char p = pat[j - 1];
+        uint16_t p = pat[j - 1];
         if (p == '%') dp[i][j] = dp[i][j - 1] || (dp[i - 1][j] && text[i - 1] != '\n');
         else if (p == '_') dp[i][j] = dp[i - 1][j - 1] && text[i - 1] != '\n';
-        else dp[i][j] = dp[i - 1][j - 1] && up(p) == up(text[i - 1]);
+        else dp[i][j] = dp[i - 1][j - 1] && p == text[i - 1];
     }
     return dp[n][m] != 0;
 }
@@ -158,7 +208,7 @@ inline std::vector<Tok> tokenize(const std::string& e) {          // FilterParse
         }
         if (isl(c) || c == '_') {
             std::string w; while (i < e.size() && (isl((unsigned char)e[i]) || isdigit((unsigned char)e[i]) || e[i] == '_')) w.push_back(e[i++]);
-            std::string u = w; for (auto& ch : u) ch = up(ch);
+            std::string u = w; for (auto& ch : u) ch = (char)up_cp((unsigned char)ch);      // keywords are ASCII
             Tok::T t = Tok::Ident;
             if (u == "AND") t = Tok::And; else if (u == "OR") t = Tok::Or; else if (u == "NOT") t = Tok::Not; else if (u == "BETWEEN") t = Tok::Between;
             else if (u == "IN") t = Tok::In; else if (u == "CONTAINS") t = Tok::Contains; else if (u == "STARTS") t = Tok::Starts; else if (u == "ENDS") t = Tok::Ends;
@@ -287,12 +337,12 @@ inline bool execute(const Compiled& f, const Fields& doc) {          // FilterVM
             case OR: { Slot r = pop(), l = pop(); pushb(asbool(l) || asbool(r)); break; }
             case NOT: { Slot v = pop(); pushb(!asbool(v)); break; }
             case CONTAINS: case STARTS_WITH: case ENDS_WITH: case LIKE: {
-                Slot p = pop(), t = pop(); std::string pat = str(p), text = str(t), P = pat, T = text;
-                for (auto& ch : P) ch = up(ch); for (auto& ch : T) ch = up(ch);
+                Slot p = pop(), t = pop(); std::string pat = str(p), text = str(t);
+                const std::vector<uint16_t> P = up_units(pat), T = up_units(text);      // StringComparison.OrdinalIgnoreCase
                 bool r;
-                if (in.op == CONTAINS) r = T.find(P) != std::string::npos;
-                else if (in.op == STARTS_WITH) r = T.size() >= P.size() && T.compare(0, P.size(), P) == 0;
-                else if (in.op == ENDS_WITH) r = T.size() >= P.size() && T.compare(T.size() - P.size(), P.size(), P) == 0;
+                if (in.op == CONTAINS) r = std::search(T.begin(), T.end(), P.begin(), P.end()) != T.end();
+                else if (in.op == STARTS_WITH) r = T.size() >= P.size() && std::equal(P.begin(), P.end(), T.begin());
+                else if (in.op == ENDS_WITH) r = T.size() >= P.size() && std::equal(P.begin(), P.end(), T.end() - (long)P.size());
                 else r = like_match(text, pat);
                 pushb(r); break; }
             case MATCHES: throw std::runtime_error("MATCHES is not restated");

@@ -268,6 +268,7 @@ int32_t orc_delete_keys(void* h, const int64_t* keys, int64_t n) {
     Handle* H = (Handle*)h; Index& ix = H->eng.ix; if (ix.deleted.empty()) ix.deleted.assign((size_t)ix.N, 0);
     std::unordered_set<int64_t> ks(keys, keys + n); int32_t c = 0;
     for (int d = 0; d < ix.N; d++) if (!ix.deleted[d] && ks.count(ix.docKey[d])) { ix.deleted[d] = 1; c++; }
+    H->filterCount.clear();      // a Filter object parsed after the deletion counts again (NumberOfDocumentsInFilter lives on the Filter instance, Api/Filter.cs:17)
     return c;
 }
 // One column of non-indexed document fields, by internal doc id. kind: 1 int64 (vals_i), 2 double (vals_d), 3 string (arena + offs, UTF-8)
@@ -277,6 +278,7 @@ void orc_set_column(void* h, const char* name, int32_t kind, int32_t facetable, 
         if (kind == 1) c.vals[i] = flt::Value::integer(vals_i[i]); else if (kind == 2) c.vals[i] = flt::Value::num(vals_d[i]);
         else c.vals[i] = flt::Value::str(std::string(arena + offs[i], arena + offs[i + 1]));
     }
+    H->filterCount.clear();
     for (auto& x : H->cols) if (x.name == c.name) { x = c; return; }
     H->cols.push_back(std::move(c));
 }
@@ -296,7 +298,8 @@ int32_t orc_search_filtered(void* h, const uint16_t* q, int32_t qlen, int32_t ma
         catch (const flt::ParseError& e) { return std::string(e.what()).find("not restated") != std::string::npos ? -2 : -1; }
         auto fc = H->filterCount.find(filter);
         if (fc == H->filterCount.end() || fc->second == 0) {                 // NumberOfDocumentsInFilter == 0 -> count over ALL documents
-            int m = 0; for (int d = 0; d < H->eng.ix.N; d++) if (flt::execute(c, H->fields_of(d))) m++;
+            // over DocumentCollection.GetAllDocuments() == the documents that are not Deleted (Core/DocumentCollection.cs:216-219)
+            int m = 0; for (int d = 0; d < H->eng.ix.N; d++) if (!H->eng.ix.is_deleted(d) && flt::execute(c, H->fields_of(d))) m++;
             H->filterCount[filter] = m;
         }
         H->lastInFilter = H->filterCount[filter];

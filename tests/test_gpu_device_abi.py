@@ -115,3 +115,60 @@ def test_device_abi_with_oracle_built_inputs():
         assert np.array_equal(fo[k, :O.N_INT_FEAT], feat[:O.N_INT_FEAT]), (q, cov_rows[k].doc, fo[k, :O.N_INT_FEAT].tolist(), feat[:O.N_INT_FEAT].tolist())
         assert outs[k].tiebreaker == tie and abs(outs[k].score - sc) <= 2.0 ** -6 + 1e-6, (q, outs[k].score, sc)
     L.infx_stream_destroy(st); L.infx_destroy(idx)
+
+
+@pytest.mark.parametrize("flags", [1, 0])          # INFX_CFG_NO_EXACT_REPLAY: the first pass alone; 0: with the replay behind it
+def test_member_list_virtual_term_counts_every_document_once(flags):
+    """infx_term.reserved == 1 (a fuzzy virtual term given as its LD1 member term ids): the union is formed inside the accumulate launch and every
+    document counts with tf == 1 (RoaringPostingsEnum.Freq, Indexing/RoaringPostingsEnum.cs:21) — also where a member's own posting has tf >= 2.
+    Expected values: the same query with the union materialised by the caller (reserved == 0), and BM25+ restated in numpy fp32 over the oracle's arrays."""
+    L = load_library()
+    s = Synth(2, docs=20000)
+    arena, offs = s.docs()
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    ex = o.export_index(); N = o.num_docs; T = o.num_terms; avgdl = np.float32(o.avgdl)
+    idx = C.c_void_p(); st = C.c_void_p()
+    cfg = Cfg(0, 0, DEPTH, flags)
+    chk(L, L.infx_create(C.byref(cfg), C.byref(idx)))
+    keys = np.arange(N, dtype=np.int64)
+    chk(L, L.infx_upload_docs(idx, N, _p(ex["doc_len"], C.c_float), C.c_float(avgdl), _p(keys, C.c_int64), None, None, None))
+    chk(L, L.infx_upload_postings(idx, T, _p(ex["post_off"], C.c_uint64), _p(ex["post_doc"], C.c_int32), _p(ex["post_w"], C.c_uint8), _p(ex["df"], C.c_int32)))
+    z = np.zeros(1, np.uint64)
+    chk(L, L.infx_upload_prefix_docsets(idx, 0, _p(z, C.c_uint64), None))
+    chk(L, L.infx_stream_create(idx, C.byref(st)))
+    po, pd, pw = ex["post_off"], ex["post_doc"], ex["post_w"]
+    # members: terms that hold postings with tf >= 2, moderately long lists, overlapping documents between members
+    cand = [t for t in range(T) if 200 <= po[t + 1] - po[t] <= 4000 and pw[int(po[t]):int(po[t + 1])].max() >= 2]
+    assert len(cand) >= 6
+    f32 = np.float32
+    norm = (f32(1.2) * (f32(f32(1) - f32(0.75)) + f32(f32(0.75) / avgdl) * ex["doc_len"].astype(np.float32))).astype(np.float32)      # Bm25Scorer.cs:413
+    qs, terms, extra, want = [], [], [], []
+    for g in range(0, 6, 3):
+        members = cand[g:g + 3]
+        docs = np.unique(np.concatenate([pd[int(po[t]):int(po[t + 1])] for t in members])).astype(np.int32)
+        df = len(docs)
+        idf = f32(np.log(f32(f32(N - df) + f32(0.5)) / f32(f32(df) + f32(0.5)) + f32(1)))
+        sc = (idf * (f32(1) * f32(2.2) / (f32(1) + norm[docs]) + f32(1))).astype(np.float32)
+        want.append(dict(zip(docs.tolist(), sc.tolist())))
+        for reserved in (1, 0):      # the same query twice: member list, then the caller's union
+            qs.append(Query(len(terms), 1, 2, -1, DEPTH, 1, 1, 0))      # INFX_MODE_DISJ, one eligible term of rank 0
+            if reserved:
+                terms.append(Term(-1, len(extra), len(members), float(idf), float(idf * 3.2), 16, 0, 1)); extra += members
+            else:
+                terms.append(Term(-1, len(extra), len(docs), float(idf), float(idf * 3.2), 16, 0, 0)); extra += docs.tolist()
+    nq = len(qs)
+    QA = (Query * nq)(*qs); TA = (Term * len(terms))(*terms); EX = np.asarray(extra, np.int32)
+    hits = (Hit * (nq * DEPTH))(); hc = np.zeros(nq, np.uint32)
+    chk(L, L.infx_stage1_batch(st, nq, QA, len(terms), TA, len(EX), _p(EX, C.c_int32), hits, _p(hc, C.c_uint32)))
+    for i in range(nq):
+        got = {hits[i * DEPTH + k].doc: hits[i * DEPTH + k].score for k in range(int(hc[i]))}
+        w = want[i // 2]
+        assert len(got) == min(DEPTH, len(w))
+        cut = sorted(w.values(), reverse=True)[len(got) - 1]
+        for d, sc in got.items():
+            assert d in w and abs(sc - w[d]) <= SCORE_RTOL * w[d], (i, d, sc, w.get(d))      # tf == 1 for every document of the union
+            assert w[d] >= cut * (1 - 1e-5)
+        if i % 2 == 1:                                                                         # member list == caller-built union, row for row
+            prev = {hits[(i - 1) * DEPTH + k].doc: hits[(i - 1) * DEPTH + k].score for k in range(int(hc[i - 1]))}
+            assert prev == got
+    L.infx_stream_destroy(st); L.infx_destroy(idx)

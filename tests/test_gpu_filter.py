@@ -6,7 +6,7 @@ import pytest
 from infidex_amd import SearchEngine, Document, Query
 from infidex_amd.engine import InfidexError
 from tests import oracle_lib as O
-from tests.test_oracle_filter_kats import VM_KATS
+from tests.test_oracle_filter_kats import VM_KATS, BCL_KATS
 from tools.synth import Synth
 
 pytestmark = pytest.mark.gpu
@@ -50,7 +50,7 @@ def test_filter_and_facets_match_the_oracle(pair, flt):
 def test_vm_known_answers_through_the_device():
     """Every VM known answer of the reference (restated in test_oracle_filter_kats.VM_KATS) evaluated by the product: one document whose fields are
     the KAT's, the expression as the post-filter of a query that returns it."""
-    for expr, fields, want in VM_KATS:
+    for expr, fields, want in VM_KATS + BCL_KATS:
         e = SearchEngine.create_default(device=0); e.index_documents([Document(1, "alpha bravo"), Document(2, "charlie delta")])
         for name, v in fields.items():
             if v is None:
@@ -71,3 +71,22 @@ def test_syntax_errors_and_unsupported():
     with pytest.raises(InfidexError):
         e.search(Query("alpha", 10, filter="a MATCHES '^1'"))
     assert [x.document_id for x in e.search(Query("alpha", 10, filter="a = '1'")).records] == [1]      # the session recovers after an error
+
+
+def test_in_filter_count_follows_deletions():
+    """Filter.NumberOfDocumentsInFilter counts the documents that are not Deleted, and a filter used after a deletion counts again."""
+    docs = [Document(k, "alpha bravo %d" % k) for k in range(1, 9)]
+    year = np.array([1990, 1995, 2000, 2005, 2010, 2015, 2020, 2025], np.int64)
+    e = SearchEngine.create_default(device=0); e.index_documents(docs); e.set_column("year", year, facetable=True)
+    o = O.OracleEngine.create_default(); o.index([(d.document_key, d.fields) for d in docs]); o.set_column("year", year, facetable=True)
+    for step in range(2):
+        r = e.search(Query("alpha", 10, filter="year >= 2000")); w = o.search_filtered("alpha", 10, filter="year >= 2000")
+        assert r.total_in_filter == w["in_filter"] == (6 if step == 0 else 4)
+        assert [x.document_id for x in r.records] == w["keys"]
+        e.delete_documents([3, 8]); o.delete_keys([3, 8])
+    e.restore_documents()
+    assert e.search(Query("alpha", 10, filter="year >= 2000")).total_in_filter == 6
+    # a column added later: filters compiled before it existed treated the field as null and are compiled again
+    assert e.search(Query("alpha", 10, filter="tag = 'x'")).total_in_filter == 0
+    e.set_column("tag", ["x", "y"] * 4)
+    assert e.search(Query("alpha", 10, filter="tag = 'x'")).total_in_filter == 4

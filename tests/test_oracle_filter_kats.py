@@ -34,7 +34,20 @@ VM_KATS = [
 ]
 
 
-@pytest.mark.parametrize("expr,fields,want", VM_KATS)
+# Not reference-held answers: .NET BCL behaviour the VM inherits (StringComparison.OrdinalIgnoreCase folds every cased character with the invariant simple
+# mapping; double.TryParse(string) = NumberStyles.Float | AllowThousands).  PARITY UNPINNED (no .NET here) — kept apart from VM_KATS on purpose; the
+# product must agree with the oracle on them (tests/test_gpu_filter.py).
+BCL_KATS = [
+    ("mesto = 'čáslav'", {"mesto": "ČÁSLAV"}, T), ("mesto = 'Žďár'", {"mesto": "žĎÁR"}, T), ("mesto != 'ŘÍČANY'", {"mesto": "říčany"}, F),
+    ("name CONTAINS 'ÉCOLE'", {"name": "grande école"}, T), ("name STARTS WITH 'ωμ'", {"name": "ΩΜΕΓΑ"}, T), ("name ENDS WITH 'СКВА'", {"name": "москва"}, T),
+    ("name LIKE 'š_ola'", {"name": "ŠKOLA"}, T), ("name LIKE 'š_ola'", {"name": "ŠKKOLA"}, F), ("name = 'ı'", {"name": "I"}, F), ("name = 'ſ'", {"name": "S"}, F),
+    ("price > 999", {"price": "1,000"}, T), ("price = 1000", {"price": "1,000"}, F),          # CompareTo parses both sides; AreEqual compares the strings
+    ("price > 999", {"price": ",1000"}, F),                                                       # not a number -> string compare: "," < "9"
+    ("price < '1,5'", {"price": 14}, T),                                                           # "1,5" parses as 15 (group separator), 14 < 15
+]
+
+
+@pytest.mark.parametrize("expr,fields,want", VM_KATS + BCL_KATS)
 def test_vm_kats(expr, fields, want):
     assert O.filter_eval(expr, fields) is want
 
@@ -77,3 +90,15 @@ def test_faceting_kats():
     assert dict(r["facets"]["genre"]) == {"Action": 1, "Drama": 1}
     r = o.search_filtered("drama", 2, filter="genre = 'crime'")
     assert len(r["keys"]) <= 2 and all(genre[k - 1] == "Crime" for k in r["keys"])   # post-filter of the <= k returned rows (ResultProcessor.cs:56-69)
+
+
+def test_number_of_documents_in_filter_skips_deleted_documents():
+    """ResultProcessor.cs:39-54 counts over DocumentCollection.GetAllDocuments() = the documents that are not Deleted (Core/DocumentCollection.cs:216-219)."""
+    import numpy as np
+    docs = [(k, "alpha bravo %d" % k) for k in range(1, 9)]
+    o = O.OracleEngine.create_default(); o.index(docs)
+    o.set_column("year", np.array([1990, 1995, 2000, 2005, 2010, 2015, 2020, 2025], np.int64), facetable=True)
+    assert o.search_filtered("alpha", 10, filter="year >= 2000")["in_filter"] == 6
+    o.delete_keys([3, 8])
+    r = o.search_filtered("alpha", 10, filter="year >= 2000")
+    assert r["in_filter"] == 4 and not ({3, 8} & set(r["keys"]))
