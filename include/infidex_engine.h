@@ -81,6 +81,16 @@ int32_t infx_session_union_counts(infx_session* s, uint32_t* counts);
 int32_t infx_session_phase1(infx_session* s, const uint32_t* global_union_counts, uint32_t* ndev);
 int32_t infx_session_counts(infx_session* s, uint32_t* counts);
 int32_t infx_session_phase2(infx_session* s, const uint32_t* global_counts, infx_hit* hits, uint32_t* hitcounts);
+/* phase 2 in three steps for the exact cut across shards (infidex_hip.h, infx_shard_replay_*); every buffer may be host or device memory:
+ *   phase2a: tier rules + first-pass top-`depth` + best score left out                 -> all-gather (hits, hitcounts, next)
+ *   phase2b: global ambiguity test + this shard's part of the replay; *blob_bytes      -> max over ranks; infx_session_phase2b_blob -> all-gather
+ *   phase2c: owner-side heap replay; hits / hitcounts = this rank's contribution         -> all-gather -> phase 3
+ *   phase2d: (only if a hitcount is 0xFFFFFFFF) sequential chain step for the queries with need[q] != 0 */
+int32_t infx_session_phase2a(infx_session* s, const void* global_counts, void* hits, void* hitcounts, void* next);
+int32_t infx_session_phase2b(infx_session* s, int32_t nranks, const void* all_hits, const void* all_hitcounts, const void* all_next, uint64_t* blob_bytes);
+int32_t infx_session_phase2b_blob(infx_session* s, void* dst, uint64_t padded_bytes);
+int32_t infx_session_phase2c(infx_session* s, int32_t nranks, const void* all_blobs, uint64_t padded_bytes, void* hits, void* hitcounts);
+int32_t infx_session_phase2d(infx_session* s, const uint32_t* need, void* state);
 int32_t infx_session_phase3(infx_session* s, int32_t nranks, const infx_hit* all_hits, const uint32_t* all_hitcounts, int32_t max_results,
                             int32_t enable_coverage, uint64_t* ncand);
 int32_t infx_session_outs(infx_session* s, int32_t* outs3);

@@ -51,7 +51,7 @@ typedef struct infx_config {
 /* Queries whose Stage-1 top-`depth` cut is ambiguous (rows within a few ulp of each other around the cut, exact ties included) are
  * replayed with the reference's sequential semantics — chunked Vector256 / scalar-tail BM25 rounding (Bm25Scorer.cs:395-444) and the
  * BCL PriorityQueue eviction order (Bm25Scorer.cs:654-670) — by k_exact1, so the Stage-1 set and scores are the reference's bit for
- * bit.  This flag turns the replay off (the cut is then taken by (score, doc id)); document shards always run without it. */
+ * bit.  This flag turns the replay off (the cut is then taken by (score, doc id)).  Document shards replay through infx_shard_replay_* (below). */
 #define INFX_CFG_NO_EXACT_REPLAY 1
 
 int32_t infx_create(const infx_config* cfg, infx_index** out);
@@ -263,7 +263,7 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
                           int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags);
 /* Document-sharded operation: the same device stages, cut where the collectives go. Rows carry GLOBAL internal ids.
  *   infx_stage1_accumulate (local) -> all-reduce(sum) of the class histograms
- *   infx_shard_select   : tier rules from the GLOBAL counts + local top-`depth`      -> all-gather of hits / hit counts (RCCL)
+ *   infx_shard_select   : tier rules from the GLOBAL counts + local first-pass top-`depth` -> all-gather; infx_shard_replay_* (exact cut) -> all-gather of hits / hit counts (RCCL)
  *   infx_shard_stage2   : merge of the nshards lists, candidate assembly, Stage 2 on the rows whose document this shard holds
  *                         (all other rows are zero)                                  -> all-reduce(sum) of outs (nq x 2*depth x 12 B)
  *   infx_shard_finalize : final ordering / truncation from the merged rows (identical on every rank).
@@ -271,7 +271,28 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
  * pointers (e.g. the tensors a torch.distributed / RCCL collective works on) are copied device-to-device, nothing crosses PCIe.
  * Every shard needs the GLOBAL DocumentKey table (infx_upload_doc_keys_all) and the WordMatcher lists (global ids). */
 int32_t infx_upload_doc_keys_all(infx_index* idx, uint32_t total_docs, const int64_t* keys);
-int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global_counts, int32_t depth, infx_hit* hits_out, uint32_t* hitcount_out);
+int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global_counts, int32_t depth, infx_hit* hits_out, uint32_t* hitcount_out,
+                          float* next_out /* nd: best first-pass score this shard left out of its list (0: none); NULL = not wanted */);
+/* The reference's Stage-1 cut across document shards, bit for bit (Bm25Scorer.cs:195-329 chunks, :350-368 MaxScore skips, :654-670 UpdateTopK on the
+ * BCL heap): shards must begin at multiples of 65 536 documents (whole Roaring containers), so the reference's sequential walk is the shards' walks one
+ * after the other, coupled only through the heap.  Between infx_shard_select and infx_shard_stage2:
+ *   infx_shard_select (hits, counts, next)                                 -> all-gather of the three                                [Exchange 2a]
+ *   infx_shard_replay_local : global ambiguity test (identical on every rank) + this shard's chunks: exact scores, candidates the heap could
+ *                             still take, validity intervals of the MaxScore skips; *blob_bytes = size of the packed result
+ *   infx_shard_replay_blob  : copies it to host or device memory             -> all-gather of the blobs, padded to the largest        [Exchange 2c]
+ *   infx_shard_replay_merge : the OWNER of a flagged query (query mod nshards) replays UpdateTopK over shard 0's chunks, then shard 1's, ...;
+ *                             hits_out / hitcount_out = this rank's contribution to the final lists: the exact list for owned flagged queries,
+ *                             nothing for other flagged queries, the first-pass list otherwise                                      -> all-gather [Exchange 2b]
+ *                             hitcount 0xFFFFFFFF: the owner could not certify the parallel replay (rare) -> infx_shard_replay_chain
+ *   infx_shard_replay_chain : the literal sequential replay of the queries with need[q] != 0, continued from shard to shard: state = nd x (2 + 2*depth)
+ *                             words {n, threshold bits, doc[depth], score bits[depth]} (heap array order), zero for shard 0; pass the output of shard r
+ *                             to shard r+1; the last shard's state is the reference's final heap.  depth == infx_config.max_depth. */
+int32_t infx_shard_replay_local(infx_stream* s, int32_t nshards, uint32_t nd, const infx_hit* all_hits /* nshards x nd x depth */, const uint32_t* all_hitcounts,
+                                const float* all_next, int32_t depth, uint64_t* blob_bytes);
+int32_t infx_shard_replay_blob(infx_stream* s, void* dst, uint64_t padded_bytes);
+int32_t infx_shard_replay_merge(infx_stream* s, int32_t nshards, uint32_t nd, const void* all_blobs /* nshards x padded_bytes */, uint64_t padded_bytes, int32_t depth,
+                                infx_hit* hits_out, uint32_t* hitcount_out);
+int32_t infx_shard_replay_chain(infx_stream* s, uint32_t nd, const uint32_t* need, int32_t depth, void* state);
 int32_t infx_shard_stage2(infx_stream* s, int32_t nshards, uint32_t nd, const infx_hit* all_hits /* nshards x nd x depth */, const uint32_t* all_hitcounts,
                           uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq, uint32_t nlists, const infx_wm_list* lists,
                           uint32_t owned_n, const int32_t* owned, int32_t depth, int32_t max_results, int32_t want_debug, infx_cov_out* outs_out);

@@ -157,9 +157,12 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
     e->keysAreIds = (keys == nullptr);
     if (keys) { e->keyToFirst.reserve((size_t)n * 2); for (int64_t d = 0; d < n; d++) e->keyToFirst.emplace(keys[d], (int32_t)d); }
     {
-        // contiguous doc-range shard: rank r owns [r*N/W, (r+1)*N/W)
-        const int64_t N = e->ix.N, W = e->nranks, r = e->rank;
-        e->shardBase = (int32_t)(N * r / W); e->shardN = (int32_t)(N * (r + 1) / W - N * r / W);
+        // contiguous doc-range shards of whole 65 536-id Roaring containers: the reference scores its candidates in chunks that never span a
+        // container (Bm25Scorer.cs:195-280), so with boundaries at container multiples its sequential walk is the shards' walks one after the other and
+        // the exact Stage-1 replay stays shard-local (exactsh.hip.inc).  Rank r owns containers [nCont*r/W, nCont*(r+1)/W) — an empty shard if W > nCont.
+        const int64_t N = e->ix.N, W = e->nranks, r = e->rank, C = 65536, nCont = (N + C - 1) / C;
+        auto bound = [&](int64_t k) { return std::min<int64_t>(N, C * (nCont * k / W)); };
+        e->shardBase = (int32_t)bound(r); e->shardN = (int32_t)(bound(r + 1) - bound(r));
     }
     if (e->dev) {
         HostIndex& ix = e->ix;
@@ -891,7 +894,7 @@ int32_t infx_session_phase2(infx_session* S, const uint32_t* global_counts, infx
     Batch& B = *S->batch;
     S->lastHits.assign((size_t)B.nd * B.depth, infx_hit{0, 0.f}); S->lastHitCount.assign(B.nd, 0); S->lastStride = B.depth;
     if (B.nd) {
-        int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, S->lastHits.data(), S->lastHitCount.data());
+        int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, S->lastHits.data(), S->lastHitCount.data(), nullptr);
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
         infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays); infx_last_replay_stats(S->stream, &S->msReplay, S->flagWhy);
@@ -903,6 +906,54 @@ int32_t infx_session_phase2(infx_session* S, const uint32_t* global_counts, infx
     if (hits) std::memcpy(hits, S->lastHits.data(), S->lastHits.size() * sizeof(infx_hit));
     if (hitcounts) std::memcpy(hitcounts, S->lastHitCount.data(), S->lastHitCount.size() * 4);
     B.t2 = now_ms();
+    return INFX_OK;
+}
+// ---- phase 2 with the exact cut across shards (infx_shard_replay_*) ----
+static void take_stage1_stats(infx_session* S, bool withHits) {
+    Batch& B = *S->batch;
+    infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
+    infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates);
+    uint64_t ab = 0;
+    for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)S->e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
+    S->algBytes = ab + S->s1Candidates * 4ull + (withHits ? (uint64_t)B.nd * B.depth * 12ull : 0ull);
+}
+int32_t infx_session_phase2a(infx_session* S, const void* global_counts, void* hits, void* hitcounts, void* next) {
+    if (!S || !global_counts || !hits || !hitcounts || !next) return efail(INFX_EINVAL, "null");
+    Batch& B = *S->batch;
+    int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, (infx_hit*)hits, (uint32_t*)hitcounts, (float*)next);     // nd == 0: resets the replay state
+    if (rc) { g_eerr = infx_last_error(); return rc; }
+    if (B.nd) take_stage1_stats(S, true);
+    return INFX_OK;
+}
+int32_t infx_session_phase2b(infx_session* S, int32_t W, const void* all_hits, const void* all_hitcounts, const void* all_next, uint64_t* blob_bytes) {
+    if (!S || W < 1 || !blob_bytes) return efail(INFX_EINVAL, "null");
+    Batch& B = *S->batch;
+    int32_t rc = infx_shard_replay_local(S->stream, W, B.nd, (const infx_hit*)all_hits, (const uint32_t*)all_hitcounts, (const float*)all_next, B.depth, blob_bytes);
+    if (rc) { g_eerr = infx_last_error(); return rc; }
+    return INFX_OK;
+}
+int32_t infx_session_phase2b_blob(infx_session* S, void* dst, uint64_t padded) {
+    if (!S || !dst) return efail(INFX_EINVAL, "null");
+    int32_t rc = infx_shard_replay_blob(S->stream, dst, padded);
+    if (rc) { g_eerr = infx_last_error(); return rc; }
+    return INFX_OK;
+}
+int32_t infx_session_phase2c(infx_session* S, int32_t W, const void* all_blobs, uint64_t padded, void* hits, void* hitcounts) {
+    if (!S || W < 1 || !hits || !hitcounts) return efail(INFX_EINVAL, "null");
+    Batch& B = *S->batch;
+    if (B.nd) {
+        int32_t rc = infx_shard_replay_merge(S->stream, W, B.nd, all_blobs, padded, B.depth, (infx_hit*)hits, (uint32_t*)hitcounts);
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+        infx_last_exact_replays(S->stream, &S->exactReplays); infx_last_replay_stats(S->stream, &S->msReplay, S->flagWhy);
+    }
+    B.t2 = now_ms();
+    return INFX_OK;
+}
+int32_t infx_session_phase2d(infx_session* S, const uint32_t* need, void* state) {
+    if (!S || !need || !state) return efail(INFX_EINVAL, "null");
+    Batch& B = *S->batch;
+    int32_t rc = infx_shard_replay_chain(S->stream, B.nd, need, B.depth, state);
+    if (rc) { g_eerr = infx_last_error(); return rc; }
     return INFX_OK;
 }
 int32_t infx_session_phase3(infx_session* S, int32_t W, const infx_hit* all_hits, const uint32_t* all_counts, int32_t max_results, int32_t enable_coverage, uint64_t* ncand) {
@@ -936,7 +987,7 @@ int32_t infx_session_phase2x(infx_session* S, const uint32_t* global_counts, voi
     if (!S || !global_counts || !hits || !hitcounts) return efail(INFX_EINVAL, "null");
     Batch& B = *S->batch;
     if (B.nd) {
-        int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, (infx_hit*)hits, (uint32_t*)hitcounts);
+        int32_t rc = infx_shard_select(S->stream, B.nd, (const infx_counts*)global_counts, B.depth, (infx_hit*)hits, (uint32_t*)hitcounts, nullptr);
         if (rc) { g_eerr = infx_last_error(); return rc; }
         infx_last_timings(S->stream, &S->msAcc, &S->msSel, nullptr);
         infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays); infx_last_replay_stats(S->stream, &S->msReplay, S->flagWhy);

@@ -161,6 +161,7 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 #include "stage1.hip.inc"
 #include "exact1.hip.inc"
 #include "exact3.hip.inc"
+#include "exactsh.hip.inc"
 #include "stage2.hip.inc"
 
 // TieredCandidateSelector tier rules evaluated from class counts (see header of this file / DESIGN.md)
@@ -267,6 +268,10 @@ struct infx_stream {
     uint64_t lastAlgBytes = 0, lastCandTotal = 0;
     bool timedAcc = false, timedSel = false, timedCov = false;
     void* dStats = nullptr;      // k_accumulate profiling counters (INFX_ACC_SKIP=8)
+    // exact replay across document shards (exactsh.hip.inc)
+    void *dNext = nullptr, *dPrior = nullptr, *shBlob = nullptr, *dAllBlobs = nullptr, *dAllNext = nullptr, *dChainState = nullptr, *dChainNeed = nullptr;
+    size_t capNext = 0, capPrior = 0, capShBlob = 0, capAllBlobs = 0, capAllNext = 0, capChainState = 0, capChainNeed = 0;
+    uint32_t shHead[4] = {0, 0, 0, 0}; uint32_t shNd = 0; int shDepth = 0; bool shSelected = false;
 };
 
 static int32_t grow(void** p, size_t* cap, size_t need) {
@@ -409,32 +414,43 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
 
 // k_exact1 behind k_select: unsharded indexes only (the reference's chunking follows GLOBAL 65 536-id containers and its heap is sequential
 // over the whole corpus; document shards keep k_select's deterministic (score, doc id) cut)
+static bool exact_slow_only() { static const bool v = [] { const char* e = getenv("INFX_EXACT_SLOW"); return e && e[0] == '1'; }(); return v; }
 static bool exact_possible(infx_stream* s) { return exact_enabled(s->ix) && s->maskWords > 0 && s->ix->nranks == 1 && s->ix->d.docBase == 0; }
-static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
+// chunk table of the parallel replay: every query needs at most (containers + reserved rows / 4096 + 2) entries
+static int32_t exact_chunk_tables(infx_stream* s, uint32_t nq, ExBufs& xb) {
     infx_index* ix = s->ix;
-    const int MW = s->maskWords, depthCap = ix->cfg.max_depth;
-    static const bool slowOnly = [] { const char* e = getenv("INFX_EXACT_SLOW"); return e && e[0] == '1'; }();      // parity tooling: k_exact1 for every flagged query
+    const int rpc = 65536 / ix->d.R, nCont = (ix->d.nRanges + rpc - 1) / rpc;
+    const size_t cap = (size_t)nq * (nCont + 2) + s->arBound / EX_CHUNK + 16;
+    if (cap > 0x7FFFFFF0ull) return fail(INFX_ECAPACITY, "exact-replay chunk table too large; split the batch%s");
+    GROW(s->exChunks, s->capExChunks, cap * sizeof(ExChunk));
+    GROW(s->exTasks, s->capExTasks, cap * 2 * 4);
+    GROW(s->exQueries, s->capExQueries, (size_t)nq * sizeof(ExQuery));
+    s->exChunkCap = (uint32_t)cap;
+    HIPCHK(hipMemsetAsync(s->exCounters, 0, 16, s->st));
+    xb = ExBufs{s->exCand, s->exOut, s->arExc, (ExChunk*)s->exChunks, s->exChunkCap, (ExQuery*)s->exQueries, s->exCounters, (uint32_t*)s->exTasks, (uint32_t*)s->exTasks + cap};
+    return INFX_OK;
+}
+static int32_t exact1_lds_ready(infx_index* ix, int MW, size_t* ldsOut) {
+    const int depthCap = ix->cfg.max_depth;
     const size_t lds1 = (size_t)(EX_CHUNK + EX_THREADS) * MW * 8 + (size_t)(EX_CHUNK + EX_THREADS) * 4 + (size_t)EX_CHUNK * 4 + (size_t)depthCap * 8 +
                         (INFX_MAX_QUERY_TERMS + 1) * 4 + 130 * 4 + 129 * 4 + 8 * 4 + (size_t)EX_CHUNK * 2 + 64;
     static std::mutex mu; static size_t attr1 = 0;
     { std::lock_guard<std::mutex> lk(mu);
       if (lds1 > attr1) { HIPCHK(hipFuncSetAttribute((const void*)k_exact1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); attr1 = lds1; } }
+    *ldsOut = lds1; return INFX_OK;
+}
+static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
+    infx_index* ix = s->ix;
+    const int MW = s->maskWords, depthCap = ix->cfg.max_depth;
+    static const bool slowOnly = exact_slow_only();      // parity tooling: k_exact1 for every flagged query
+    size_t lds1 = 0; { int32_t rc_ = exact1_lds_ready(ix, MW, &lds1); if (rc_) return rc_; }
     Arena ar = make_arena(s);
     HIPCHK(hipMemsetAsync(s->dExactStat, 0, 16, s->st));
     HIPCHK(hipEventRecord(s->evX0, s->st));
     const bool fast = !slowOnly && depthCap <= EXS_MAXDEPTH;
     if (fast) {
-        // chunk table: every query needs at most (containers + reserved rows / 4096 + 2) entries
-        const int rpc = 65536 / ix->d.R, nCont = (ix->d.nRanges + rpc - 1) / rpc;
-        const size_t cap = (size_t)nq * (nCont + 2) + s->arBound / EX_CHUNK + 16;
-        if (cap > 0x7FFFFFF0ull) return fail(INFX_ECAPACITY, "exact-replay chunk table too large; split the batch%s");
-        GROW(s->exChunks, s->capExChunks, cap * sizeof(ExChunk));
-        GROW(s->exTasks, s->capExTasks, cap * 2 * 4);
-        GROW(s->exQueries, s->capExQueries, (size_t)nq * sizeof(ExQuery));
-        s->exChunkCap = (uint32_t)cap;
-        HIPCHK(hipMemsetAsync(s->exCounters, 0, 16, s->st));
-        ExBufs xb{s->exCand, s->exOut, s->arExc, (ExChunk*)s->exChunks, s->exChunkCap, (ExQuery*)s->exQueries, s->exCounters, (uint32_t*)s->exTasks, (uint32_t*)s->exTasks + cap};
-        k_ex_scan<<<nq, EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb);
+        ExBufs xb; { int32_t rc_ = exact_chunk_tables(s, nq, xb); if (rc_) return rc_; }
+        k_ex_scan<<<nq, EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, nullptr);
         k_ex_chunk<EXC_SMALL><<<8192, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksSmall, 1, ix->avgdl);
         k_ex_chunk<EXC_BIG><<<2048, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 2, ix->avgdl);
         static const bool exProf = getenv("INFX_EXACT_PROF") != nullptr;     // k_ex_heap counters (profiling only)
@@ -446,7 +462,7 @@ static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
                               (double)h[5] / h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0]); }
     }
     k_exact1<<<nq, EX_THREADS, lds1, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag,
-                                             fast ? 2u : 1u, ix->avgdl, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, depthCap, s->dExactStat);
+                                             fast ? 2u : 1u, ix->avgdl, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, depthCap, s->dExactStat, nullptr, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evX1, s->st)); s->timedReplay = true;
     DOWN(s->lastExact2, s->dExactStat, 8);          // [0] replayed queries, [1] of them through the sequential k_exact1 fallback; lands at the caller's synchronisation
@@ -650,7 +666,8 @@ void infx_stream_destroy(infx_stream* s) {
     hipSetDevice(s->ix->cfg.device);
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
-                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters};
+                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters,
+                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed};
     for (void* p : ps) if (p) hipFree(p);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
@@ -832,7 +849,7 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     HIPCHK(hipEventRecord(s->evS0, s->st));
     const bool exact = exact_possible(s);
     if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
-    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr);
+    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr, nullptr);
     if (exact) { int32_t rc_ = enqueue_exact(s, nq, maxDepth); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evS1, s->st));
@@ -922,7 +939,7 @@ static int32_t fused_check_queries(infx_index* ix, uint32_t nd, uint32_t nq, con
 }
 
 // k_rules (from the class histogram in s->dCounts) + k_select -> s->dHits / s->dHitCount (stride = depth)
-static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth) {
+static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, bool shardNext = false) {
     infx_index* ix = s->ix;
     GROW(s->dRules, s->capRules, std::max<size_t>(1, nd) * sizeof(SelRule));
     GROW(s->dHits, s->capHits, std::max<size_t>(1, (size_t)nd) * depth * sizeof(infx_hit));
@@ -934,9 +951,11 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth) 
     HIPCHK(hipEventRecord(s->evS0, s->st));
     if (nd) {
         k_rules<<<(nd + 255) / 256, 256, 0, s->st>>>((const infx_query*)s->dFQueries, (const uint32_t*)s->dCounts, (SelRule*)s->dRules, nd);
-        const bool exact = exact_possible(s);
+        const bool exact = !shardNext && exact_possible(s);
         if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
-        k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr);
+        if (shardNext) GROW(s->dNext, s->capNext, (size_t)nd * 4);       // document shards: no local flags — the cut is global (k_gflag)
+        k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr,
+                                                shardNext ? (float*)s->dNext : nullptr);
         if (exact) { int32_t rc_ = enqueue_exact(s, nd, depth); if (rc_) return rc_; }
     }
     HIPCHK(hipGetLastError());
@@ -1094,18 +1113,21 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
 }
 
 // ---- document-sharded operation: the same device stages with the collectives of SURVEY 8(e) in between (host buffers) ----------
-int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global_counts, int32_t depth, infx_hit* hits_out, uint32_t* hitcount_out) {
+int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global_counts, int32_t depth, infx_hit* hits_out, uint32_t* hitcount_out, float* next_out) {
     if (!s || (nd && (!global_counts || !hits_out || !hitcount_out))) return fail(INFX_EINVAL, "null argument%s");
+    if (s) { s->shSelected = false; s->shNd = 0; s->shHead[0] = s->shHead[1] = s->shHead[2] = 0; }
     if (nd == 0) return INFX_OK;
     if (nd != s->lastNq) return fail(INFX_EINVAL, "infx_shard_select must follow infx_stage1_accumulate of the same batch%s");
     infx_index* ix = s->ix;
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     UPX(s->dCounts, global_counts, (size_t)nd * INFX_NCLASS * 4);         // the tier rules see the GLOBAL cardinalities (quirk Q11); host or device memory
-    { int32_t rc_ = fused_enqueue_select(s, nd, depth); if (rc_) return rc_; }
+    { int32_t rc_ = fused_enqueue_select(s, nd, depth, true); if (rc_) return rc_; }
     std::vector<SelRule> rules(nd);
     DOWNX(hits_out, s->dHits, (size_t)nd * depth * sizeof(infx_hit));
     DOWNX(hitcount_out, s->dHitCount, (size_t)nd * 4);
+    if (next_out) DOWNX(next_out, s->dNext, (size_t)nd * 4);
+    s->shSelected = true; s->shNd = nd; s->shDepth = depth;
     DOWN(rules.data(), s->dRules, (size_t)nd * sizeof(SelRule));
     SYNC();
     s->lastCandTotal = 0; for (auto& r : rules) s->lastCandTotal += r.total;
@@ -1151,6 +1173,131 @@ int32_t infx_shard_finalize(infx_stream* s, uint32_t nq, const infx_cov_out* mer
     SYNC();
     (void)err;     // candidates outside the Stage-2 envelope are skipped per query (result flag bit 3), they no longer fail the batch
     fused_scatter_results(nq, max_results, R, out_keys, out_scores, out_ties, out_counts);
+    return INFX_OK;
+}
+
+// ---- exact Stage-1 replay across document shards (exactsh.hip.inc) ----------------------------------------------------------------------------------
+static bool shard_exact_possible(infx_stream* s) { return exact_enabled(s->ix) && s->maskWords > 0 && s->ix->cfg.max_depth <= EXS_MAXDEPTH; }
+
+int32_t infx_shard_replay_local(infx_stream* s, int32_t nshards, uint32_t nd, const infx_hit* all_hits, const uint32_t* all_hitcounts, const float* all_next,
+                                int32_t depth, uint64_t* blob_bytes) {
+    if (!s || nshards < 1 || !blob_bytes || (nd && (!all_hits || !all_hitcounts || !all_next))) return fail(INFX_EINVAL, "null argument%s");
+    *blob_bytes = shx_blob_bytes(nd, 0, 0);
+    infx_index* ix = s->ix;
+    if (nd == 0) { s->shHead[0] = 0; s->shHead[1] = s->shHead[2] = 0; return INFX_OK; }
+    if (!s->shSelected || nd != s->shNd || depth != s->shDepth) return fail(INFX_EINVAL, "infx_shard_replay_local must follow infx_shard_select of the same batch%s");
+    if (nshards != ix->nranks) return fail(INFX_EINVAL, "nshards differs from infx_set_shard%s");
+    if (ix->nranks > 1 && (ix->d.docBase & 0xFFFF)) return fail(INFX_EINVAL, "exact replay across shards needs shard boundaries at multiples of 65536 documents (whole Roaring containers)%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    const uint32_t Dall = pow2_at_least((uint32_t)nshards * (uint32_t)depth, 8);
+    if (Dall > 16384) return fail(INFX_ECAPACITY, "shards x depth exceeds the in-LDS merge (16384 rows)%s");
+    const size_t nh = (size_t)nshards * nd * depth;
+    GROW(s->dFHitsAll, s->capFHitsAll, nh * sizeof(infx_hit));
+    GROW(s->dFHcAll, s->capFHcAll, (size_t)nshards * nd * 4);
+    GROW(s->dAllNext, s->capAllNext, (size_t)nshards * nd * 4);
+    GROW(s->dPrior, s->capPrior, (size_t)nd * EXS_MAXDEPTH * 4);
+    UPX(s->dFHitsAll, all_hits, nh * sizeof(infx_hit));
+    UPX(s->dFHcAll, all_hitcounts, (size_t)nshards * nd * 4);
+    UPX(s->dAllNext, all_next, (size_t)nshards * nd * 4);
+    const bool possible = shard_exact_possible(s);
+    HIPCHK(hipMemsetAsync(s->dExactStat, 0, 32, s->st));
+    HIPCHK(hipEventRecord(s->evX0, s->st));
+    {
+        const size_t lds = (size_t)Dall * 8 + 257 * 4;
+        static std::mutex mu; static size_t attr = 0;
+        { std::lock_guard<std::mutex> lk(mu); if (lds > 64 * 1024 && lds > attr) { HIPCHK(hipFuncSetAttribute((const void*)k_gflag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; } }
+        k_gflag<<<nd, 256, lds, s->st>>>(ix->d, nshards, (int)nd, depth, (int)Dall, (const infx_hit*)s->dFHitsAll, (const uint32_t*)s->dFHcAll, (const float*)s->dAllNext,
+                                        (uint32_t*)s->dExactFlag, (float*)s->dPrior, s->dExactStat + 4, possible ? 1 : 0);
+    }
+    ExBufs xb{};
+    if (possible) {
+        Arena ar = make_arena(s);
+        { int32_t rc_ = exact_chunk_tables(s, nd, xb); if (rc_) return rc_; }
+        k_ex_scan<<<nd, EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, ix->d.docBase > 0 ? (const float*)s->dPrior : nullptr);
+        k_ex_chunk<EXC_SMALL><<<8192, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksSmall, 1, ix->avgdl);
+        k_ex_chunk<EXC_BIG><<<2048, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 2, ix->avgdl);
+        // worst case: every reserved row of every flagged query is emitted
+        const size_t need = shx_blob_bytes(nd, s->exChunkCap, 0) + s->exCap * sizeof(infx_hit);
+        GROW(s->shBlob, s->capShBlob, need);
+        k_exsh_count<<<(nd + 255) / 256, 256, 0, s->st>>>(nd, (const uint32_t*)s->dExactFlag, xb, (ShQHdr*)((unsigned char*)s->shBlob + 16));
+        k_exsh_scan<<<1, 256, 0, s->st>>>(nd, (ShQHdr*)((unsigned char*)s->shBlob + 16), (uint32_t*)s->shBlob);
+        k_exsh_copy<<<nd, 256, 0, s->st>>>(nd, (const uint32_t*)s->dExactFlag, ar, xb, (unsigned char*)s->shBlob);
+        HIPCHK(hipGetLastError());
+        DOWN(s->shHead, s->shBlob, 16);
+    } else {
+        GROW(s->shBlob, s->capShBlob, shx_blob_bytes(nd, 0, 0));
+        HIPCHK(hipMemsetAsync(s->shBlob, 0, shx_blob_bytes(nd, 0, 0), s->st));
+        const uint32_t head[4] = {nd, 0, 0, 0};
+        UP(s->shBlob, head, 16);
+        s->shHead[0] = nd; s->shHead[1] = s->shHead[2] = s->shHead[3] = 0;
+    }
+    HIPCHK(hipGetLastError());
+    DOWN(s->lastFlagWhy, s->dExactStat + 4, 16);
+    SYNC();
+    *blob_bytes = shx_blob_bytes(nd, s->shHead[1], s->shHead[2]);
+    return INFX_OK;
+}
+
+int32_t infx_shard_replay_blob(infx_stream* s, void* dst, uint64_t padded_bytes) {
+    if (!s || !dst) return fail(INFX_EINVAL, "null argument%s");
+    const size_t have = shx_blob_bytes(s->shNd, s->shHead[1], s->shHead[2]);
+    if (!s->shNd) return INFX_OK;
+    if (padded_bytes < have) return fail(INFX_EINVAL, "padded size below this shard's blob%s");
+    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    DOWNX(dst, s->shBlob, have);       // the padding beyond `have` is never read (the header says how much is valid)
+    SYNC();
+    return INFX_OK;
+}
+
+int32_t infx_shard_replay_merge(infx_stream* s, int32_t nshards, uint32_t nd, const void* all_blobs, uint64_t padded_bytes, int32_t depth,
+                                infx_hit* hits_out, uint32_t* hitcount_out) {
+    if (!s || nshards < 1 || (nd && (!all_blobs || !hits_out || !hitcount_out))) return fail(INFX_EINVAL, "null argument%s");
+    if (nd == 0) return INFX_OK;
+    infx_index* ix = s->ix;
+    if (!s->shSelected || nd != s->shNd || depth != s->shDepth || nshards != ix->nranks) return fail(INFX_EINVAL, "infx_shard_replay_merge must follow infx_shard_replay_local of the same batch%s");
+    if (padded_bytes < shx_blob_bytes(nd, 0, 0)) return fail(INFX_EINVAL, "blob size below the header%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    GROW(s->dAllBlobs, s->capAllBlobs, (size_t)nshards * padded_bytes);
+    UPX(s->dAllBlobs, all_blobs, (size_t)nshards * padded_bytes);
+    HIPCHK(hipMemsetAsync(s->dExactStat, 0, 16, s->st));
+    k_ex_heap_sh<<<nd, WAVE, 0, s->st>>>(nshards, ix->rank, nd, (const unsigned char*)s->dAllBlobs, (size_t)padded_bytes, (const uint32_t*)s->dExactFlag, depth,
+                                         exact_slow_only() ? 1 : 0, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, s->dExactStat);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->evX1, s->st)); s->timedReplay = true;
+    DOWNX(hits_out, s->dHits, (size_t)nd * depth * sizeof(infx_hit));
+    DOWNX(hitcount_out, s->dHitCount, (size_t)nd * 4);
+    uint32_t st4[4] = {0, 0, 0, 0};
+    DOWN(st4, s->dExactStat, 16);
+    SYNC();
+    s->lastExact2[0] = st4[0]; s->lastExact2[1] = st4[2];       // owned queries replayed here; of the owned ones, handed to the sequential chain
+    return INFX_OK;
+}
+
+int32_t infx_shard_replay_chain(infx_stream* s, uint32_t nd, const uint32_t* need, int32_t depth, void* state) {
+    if (!s || (nd && (!need || !state))) return fail(INFX_EINVAL, "null argument%s");
+    if (nd == 0) return INFX_OK;
+    infx_index* ix = s->ix;
+    if (!s->shSelected || nd != s->shNd || depth != s->shDepth) return fail(INFX_EINVAL, "infx_shard_replay_chain must follow infx_shard_select of the same batch%s");
+    if (!shard_exact_possible(s)) return fail(INFX_EINVAL, "no hit masks were kept for this batch: nothing to replay%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    const int depthCap = ix->cfg.max_depth;
+    if (depth != depthCap) return fail(INFX_EINVAL, "the chained replay exchanges heaps of infx_config.max_depth entries: search with that depth%s");
+    const size_t words = (size_t)nd * (2 + 2 * (size_t)depthCap);
+    GROW(s->dChainState, s->capChainState, words * 4);
+    GROW(s->dChainNeed, s->capChainNeed, (size_t)nd * 4);
+    UPX(s->dChainState, state, words * 4);
+    UPX(s->dChainNeed, need, (size_t)nd * 4);
+    size_t lds1 = 0; { int32_t rc_ = exact1_lds_ready(ix, s->maskWords, &lds1); if (rc_) return rc_; }
+    Arena ar = make_arena(s);
+    k_exact1<<<nd, EX_THREADS, lds1, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag,
+                                             0u, ix->avgdl, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, depthCap, nullptr, (uint32_t*)s->dChainState, (const uint32_t*)s->dChainNeed);
+    HIPCHK(hipGetLastError());
+    DOWNX(state, s->dChainState, words * 4);
+    SYNC();
     return INFX_OK;
 }
 

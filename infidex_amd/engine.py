@@ -182,6 +182,12 @@ class SearchEngine:
         self._check(self.L.infx_engine_delete_documents(self.h, _p(k, C.c_int64), C.c_int64(len(k)), C.byref(marked)))
         return int(marked.value)
 
+    def shard_info(self):
+        """(first internal id, number of documents) of the doc range this engine's GPU holds (the whole corpus when unsharded)."""
+        b = C.c_int32(0); n = C.c_int32(0)
+        self._check(self.L.infx_engine_shard_info(self.h, C.byref(b), C.byref(n)))
+        return int(b.value), int(n.value)
+
     def restore_documents(self):
         """Clears every Deleted flag."""
         self._check(self.L.infx_engine_restore_documents(self.h))

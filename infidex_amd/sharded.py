@@ -1,14 +1,24 @@
 """Document-sharded search across the GPUs of one node.
 
 One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gloo" for CPU tests of the plumbing).
-Every rank indexes the whole corpus on the host (global df / avgdl / N, exactly like the reference's single index), uploads
-its contiguous doc range, and runs each batch as four phases of the C++ engine with three small collectives in between:
+Every rank indexes the whole corpus on the host (global df / avgdl / N, exactly like the reference's single index), uploads its
+contiguous doc range — whole 65 536-id Roaring containers, so the reference's chunked walk (Bm25Scorer.cs:195-280) never straddles
+two shards — and runs each batch as phases of the C++ engine with small collectives in between:
 
-    phase0  text prep, LD1 member lists, k_union_count -> all-reduce(sum)  |union| of new fuzzy virtual terms (Exchange 1b)
-    phase1  idf/roles + k_accumulate                 -> all-reduce(sum)  class histograms   (Exchange 1: tier decisions, quirk Q11)
-    phase2  k_select with the GLOBAL counts          -> all-gather       per-shard top-`depth` (Exchange 2: the north-star collective)
-    phase3  merge, Stage-2 prep, k_stage2 on OWNED candidates -> all-reduce(sum) of the disjoint 12-byte records
-    phase4  final ordering / truncation (identical on every rank)
+    phase0   text prep, LD1 member lists, k_union_count     -> all-reduce(sum)  |union| of new fuzzy virtual terms   (Exchange 1b)
+    phase1   idf/roles + k_accumulate                       -> all-reduce(sum)  class histograms (tier decisions, Q11) (Exchange 1)
+    phase2a  k_select with the GLOBAL counts: first-pass top-`depth` + best score left out -> all-gather               (Exchange 2a)
+    phase2b  global ambiguity test + this shard's part of the exact replay (chunks, exact scores, validity intervals)
+                                                            -> all-gather of the packed candidates                     (Exchange 2c)
+    phase2c  the owner of a flagged query (q mod W) replays the reference's heap over shard 0's chunks, shard 1's, ...
+                                                            -> all-gather of the final per-rank lists                  (Exchange 2b: the
+                                                               north-star collective — RCCL all-gather of per-shard top-k over xGMI)
+    [phase2d sequential chain for queries the parallel replay could not certify: rare]
+    phase3   merge, Stage-2 prep, k_stage2 on OWNED candidates -> all-reduce(sum) of the disjoint 12-byte records
+    phase4   final ordering / truncation (identical on every rank)
+
+The same driver (`_run_batch`) serves real ranks (one local session, torch.distributed collectives) and the single-process
+simulation of W shards on one GPU (W local sessions, the "collectives" are numpy / torch ops) that the parity tests use.
 """
 import ctypes as C
 from typing import List, Sequence
@@ -18,6 +28,14 @@ import numpy as np
 from .engine import SearchEngine, Session, _p, INFX_NFEAT  # noqa: F401
 
 INFX_NCLASS = 136
+CHAIN = 0xFFFFFFFF
+
+
+def _vp(x):
+    """void* of a numpy array or a torch tensor (host or device)."""
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return x.ctypes.data_as(C.c_void_p)
 
 
 class TorchComm:
@@ -85,12 +103,14 @@ def create_sharded_engine(rank: int, world: int, device: int, **kw) -> SearchEng
 
 
 class ShardSession:
-    """Phase-level access to one engine session (used by ShardedSearcher and by the single-process shard simulation)."""
+    """Phase-level access to one engine session.  Exchange buffers are numpy arrays (host) or torch CUDA tensors (RCCL works on them in place)."""
 
     def __init__(self, engine: SearchEngine):
         self.e = engine
         self.L = engine.L
         self.s = Session(engine)
+        self.nq = self.nd = 0
+        self.depth = 500
 
     def prefetch_collect(self, arena, offs, begin, end, depth):
         """This rank's share of the batch's index-wide host lookups (LD1 expansions, WordMatcher descriptors of queries [begin, end)) as bytes."""
@@ -117,85 +137,194 @@ class ShardSession:
             self.e._check(self.L.infx_session_union_counts(self.s.h, _p(uc, C.c_uint32)))
         return uc[:nu.value]
 
-    def phase1(self, global_union_counts):
+    def phase1(self, global_union_counts, counts):
+        """counts: (>= nq) x INFX_NCLASS int32, host or device: this shard's class histograms are written into its first nd rows."""
         nd = C.c_uint32(0)
         guc = np.ascontiguousarray(global_union_counts, np.uint32)
         if guc.size == 0:
             guc = np.zeros(1, np.uint32)
-        self.e._check(self.L.infx_session_phase1(self.s.h, _p(guc, C.c_uint32), C.byref(nd)))
-        self.nd = nd.value
-        counts = np.zeros((max(self.nd, 1), INFX_NCLASS), np.uint32)
-        if self.nd:
-            self.e._check(self.L.infx_session_counts(self.s.h, _p(counts, C.c_uint32)))
-        return counts[:self.nd]
-
-    def phase2(self, global_counts):
-        hits = np.zeros((max(self.nd, 1), self.depth, 2), np.int32)     # (doc:int32, score bits:int32)
-        hc = np.zeros(max(self.nd, 1), np.uint32)
-        gc = np.ascontiguousarray(global_counts, np.uint32)
-        if gc.size == 0:
-            gc = np.zeros((1, INFX_NCLASS), np.uint32)
-        self.e._check(self.L.infx_session_phase2(self.s.h, _p(gc, C.c_uint32), hits.ctypes.data_as(C.c_void_p), _p(hc, C.c_uint32)))
-        return hits[:self.nd], hc[:self.nd]
-
-    def phase3(self, all_hits, all_hc, max_results, enable_coverage=True):
-        W = all_hits.shape[0]
-        ah = np.ascontiguousarray(all_hits, np.int32)
-        ac = np.ascontiguousarray(all_hc, np.uint32)
-        if ah.size == 0:
-            ah = np.zeros((W, 1, self.depth, 2), np.int32); ac = np.zeros((W, 1), np.uint32)
-        ncand = C.c_uint64(0)
-        self.max_results = max_results
-        self.e._check(self.L.infx_session_phase3(self.s.h, W, ah.ctypes.data_as(C.c_void_p), _p(ac, C.c_uint32), max_results, int(enable_coverage), C.byref(ncand)))
-        self.ncand = ncand.value
-        outs = np.zeros((max(self.ncand, 1), 3), np.int32)
-        if self.ncand:
-            self.e._check(self.L.infx_session_outs(self.s.h, _p(outs, C.c_int32)))
-        return outs[:self.ncand]
-
-    # ---- device-resident exchange buffers (torch CUDA tensors; RCCL works on them in place) ----
-    def phase1_dev(self, global_union_counts, counts_t):
-        """phase 1 with the class histograms written into counts_t (nq x INFX_NCLASS int32 CUDA tensor): Exchange 1 all-reduces it in place."""
-        nd = C.c_uint32(0)
-        guc = np.ascontiguousarray(global_union_counts, np.uint32)
-        if guc.size == 0:
-            guc = np.zeros(1, np.uint32)
-        self.e._check(self.L.infx_session_phase1x(self.s.h, _p(guc, C.c_uint32), C.c_void_p(counts_t.data_ptr()), C.byref(nd)))
+        self.e._check(self.L.infx_session_phase1x(self.s.h, _p(guc, C.c_uint32), _vp(counts), C.byref(nd)))
         self.nd = nd.value
 
-    def phase2_dev(self, global_counts, hits_t, hc_t):
-        if hasattr(global_counts, "data_ptr"):       # device tensor: read back from HBM by the engine, no host round trip
-            self.e._check(self.L.infx_session_phase2x(self.s.h, C.c_void_p(global_counts.data_ptr()), C.c_void_p(hits_t.data_ptr()), C.c_void_p(hc_t.data_ptr())))
-            return
-        gc = np.ascontiguousarray(global_counts, np.uint32)
-        if gc.size == 0:
-            gc = np.zeros((1, INFX_NCLASS), np.uint32)
-        self.e._check(self.L.infx_session_phase2x(self.s.h, _p(gc, C.c_uint32), C.c_void_p(hits_t.data_ptr()), C.c_void_p(hc_t.data_ptr())))
+    def phase2a(self, global_counts, hits, hc, nxt):
+        self.e._check(self.L.infx_session_phase2a(self.s.h, _vp(global_counts), _vp(hits), _vp(hc), _vp(nxt)))
 
-    def phase3_dev(self, all_hits_t, all_hc_t, outs_t, max_results, enable_coverage=True):
-        W = all_hits_t.shape[0]
+    def phase2b(self, W, all_hits, all_hc, all_next) -> int:
+        nb = C.c_uint64(0)
+        self.e._check(self.L.infx_session_phase2b(self.s.h, W, _vp(all_hits), _vp(all_hc), _vp(all_next), C.byref(nb)))
+        return int(nb.value)
+
+    def phase2b_blob(self, dst, padded):
+        self.e._check(self.L.infx_session_phase2b_blob(self.s.h, _vp(dst), C.c_uint64(padded)))
+
+    def phase2c(self, W, all_blobs, padded, hits, hc):
+        self.e._check(self.L.infx_session_phase2c(self.s.h, W, _vp(all_blobs), C.c_uint64(padded), _vp(hits), _vp(hc)))
+
+    def phase2d(self, need, state):
+        need = np.ascontiguousarray(need, np.uint32)
+        self.e._check(self.L.infx_session_phase2d(self.s.h, _p(need, C.c_uint32), _vp(state)))
+
+    def phase3(self, W, all_hits, all_hc, outs, max_results, enable_coverage=True):
         self.max_results = max_results
-        self.e._check(self.L.infx_session_phase3x(self.s.h, W, C.c_void_p(all_hits_t.data_ptr()), C.c_void_p(all_hc_t.data_ptr()), max_results, int(enable_coverage),
-                                                  C.c_void_p(outs_t.data_ptr())))
+        self.e._check(self.L.infx_session_phase3x(self.s.h, W, _vp(all_hits), _vp(all_hc), max_results, int(enable_coverage), _vp(outs)))
 
-    def phase4_dev(self, merged_t):
+    def phase4(self, merged):
         nq, mr = self.nq, self.max_results
         keys = np.full((nq, mr), -1, np.int64); scores = np.zeros((nq, mr), np.float32)
         ties = np.zeros((nq, mr), np.uint8); counts = np.zeros(nq, np.uint32); flags = np.zeros(nq, np.uint32)
-        self.e._check(self.L.infx_session_phase4(self.s.h, C.c_void_p(merged_t.data_ptr()), _p(keys, C.c_int64), _p(scores, C.c_float), _p(ties, C.c_uint8),
+        self.e._check(self.L.infx_session_phase4(self.s.h, _vp(merged), _p(keys, C.c_int64), _p(scores, C.c_float), _p(ties, C.c_uint8),
                                                  _p(counts, C.c_uint32), _p(flags, C.c_uint32)))
         return keys, scores, ties, counts, flags
 
-    def phase4(self, merged_outs):
-        nq, mr = self.nq, self.max_results
-        keys = np.full((nq, mr), -1, np.int64); scores = np.zeros((nq, mr), np.float32)
-        ties = np.zeros((nq, mr), np.uint8); counts = np.zeros(nq, np.uint32); flags = np.zeros(nq, np.uint32)
-        mo = np.ascontiguousarray(merged_outs, np.int32)
-        if mo.size == 0:
-            mo = np.zeros((1, 3), np.int32)
-        self.e._check(self.L.infx_session_phase4(self.s.h, _p(mo, C.c_int32), _p(keys, C.c_int64), _p(scores, C.c_float), _p(ties, C.c_uint8),
-                                                 _p(counts, C.c_uint32), _p(flags, C.c_uint32)))
-        return keys, scores, ties, counts, flags
+
+# ---- exchanges: what differs between real ranks and the in-process simulation ---------------------------------------------------------
+class _HostBufs:
+    """numpy exchange buffers (gloo, or the host-buffer simulation)."""
+    device = None
+
+    def new(self, shape, dtype):
+        return np.zeros(shape, dtype)
+
+    def host(self, x):
+        return x
+
+    def like_host(self, a):
+        return np.ascontiguousarray(a)
+
+    def sync(self):
+        pass
+
+
+class _DevBufs:
+    """torch CUDA exchange buffers (RCCL, or the device-tensor simulation).  Allocations and fills run on torch's stream, the engine works on
+    its own: sync() orders them (the engine calls are synchronous themselves)."""
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        self._dt = {np.dtype(np.int32): torch.int32, np.dtype(np.uint32): torch.int32, np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8}
+
+    def new(self, shape, dtype):
+        return self.torch.zeros(shape, dtype=self._dt[np.dtype(dtype)], device=self.device)
+
+    def host(self, x):
+        return x.cpu().numpy()
+
+    def like_host(self, a):
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.uint32:
+            a = a.view(np.int32)
+        return self.torch.from_numpy(a).to(self.device)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class _LocalX:
+    """W shards simulated in one process: the participants' buffers are combined with numpy / torch ops instead of collectives."""
+
+    def __init__(self, W, bufs):
+        self.world = W; self.b = bufs; self.ranks = list(range(W))
+
+    def allreduce_sum(self, xs):
+        if self.b.device is None or isinstance(xs[0], np.ndarray):
+            r = np.sum(np.stack(xs).astype(np.int64), axis=0).astype(xs[0].dtype)
+        else:
+            r = self.b.torch.stack(xs).sum(dim=0, dtype=xs[0].dtype).contiguous()
+        return [r] * len(xs)
+
+    def allgather(self, xs):
+        r = np.stack(xs) if self.b.device is None else self.b.torch.stack(xs).contiguous()
+        return [r] * len(xs)
+
+    def max_int(self, vs):
+        return max(vs)
+
+    def chain(self, sessions, need, state):
+        for s in sessions:                               # shard 0, 1, ...: one heap continued from shard to shard
+            s.phase2d(need, state)
+        return state
+
+
+class _DistX:
+    """One real rank: torch.distributed collectives (RCCL on device tensors, gloo on numpy)."""
+
+    def __init__(self, comm: TorchComm, bufs):
+        self.c = comm; self.world = comm.world; self.b = bufs; self.ranks = [comm.rank]
+
+    def allreduce_sum(self, xs):
+        x = xs[0]
+        if self.b.device is None or isinstance(x, np.ndarray):
+            return [self.c.allreduce_sum_i32(x) if x.size else x]
+        self.c.dist.all_reduce(x, op=self.c.dist.ReduceOp.SUM)         # in place on the tensor the kernels wrote
+        return [x]
+
+    def allgather(self, xs):
+        x = xs[0]
+        if self.b.device is None:
+            return [self.c.allgather(x)]
+        out = self.b.torch.empty((self.world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        self.c.dist.all_gather_into_tensor(out, x.contiguous())
+        return [out]
+
+    def max_int(self, vs):
+        return self.c.max_i64(int(vs[0]))
+
+    def chain(self, sessions, need, state):
+        for r in range(self.world):                      # W sequential steps: rank r continues the heap rank r-1 left
+            if r == self.c.rank:
+                sessions[0].phase2d(need, state)
+            state = self.c.allgather(state)[r].copy()
+        return state
+
+
+def _run_batch(sessions: Sequence[ShardSession], X, ucs, max_results, depth, enable_coverage):
+    """All phases after phase 0 for the local participants `sessions` (X.ranks) of a world of X.world shards."""
+    B = X.b; W = X.world; s0 = sessions[0]; nq = s0.nq
+    gucs = X.allreduce_sum([np.ascontiguousarray(u, np.uint32) for u in ucs]) if ucs[0].size else ucs          # Exchange 1b: df of new fuzzy unions (host: idf is computed there)
+    counts = [B.new((max(nq, 1), INFX_NCLASS), np.int32) for _ in sessions]
+    B.sync()
+    for s, g, c in zip(sessions, gucs, counts):
+        s.phase1(g, c)
+    gcounts = X.allreduce_sum(counts)                                                                          # Exchange 1: tier decisions need GLOBAL cardinalities (Q11)
+    nd = max(s0.nd, 1)
+    hits = [B.new((nd, depth, 2), np.int32) for _ in sessions]; hcs = [B.new((nd,), np.int32) for _ in sessions]; nxt = [B.new((nd,), np.float32) for _ in sessions]
+    B.sync()
+    for s, g, h, c, n in zip(sessions, gcounts, hits, hcs, nxt):
+        s.phase2a(g, h, c, n)
+    ah, ac, an = X.allgather(hits), X.allgather(hcs), X.allgather(nxt)                                         # Exchange 2a: first-pass lists + best score left out
+    B.sync()
+    sizes = [s.phase2b(W, h, c, n) for s, h, c, n in zip(sessions, ah, ac, an)]
+    pad = (X.max_int(sizes) + 15) & ~15
+    blobs = [B.new((pad,), np.uint8) for _ in sessions]
+    B.sync()
+    for s, b in zip(sessions, blobs):
+        s.phase2b_blob(b, pad)
+    ab = X.allgather(blobs)                                                                                    # Exchange 2c: candidates the heap could still take
+    B.sync()
+    for s, b, h, c in zip(sessions, ab, hits, hcs):
+        s.phase2c(W, b, pad, h, c)                                                                             # hits / hcs now hold this rank's FINAL contribution
+    fh, fc = X.allgather(hits), X.allgather(hcs)                                                               # Exchange 2b: the all-gather of per-shard top-k
+    B.sync()
+    fc_h = B.host(fc[0]).view(np.uint32)
+    need = (fc_h == CHAIN).any(axis=0)
+    if need.any():                                                                                             # rare: the literal sequential replay, shard after shard
+        state = X.chain(sessions, need.astype(np.uint32), np.zeros((nd, 2 + 2 * depth), np.uint32))
+        fh_h = B.host(fh[0]).copy(); fc_h = fc_h.copy()
+        for q in np.nonzero(need)[0]:
+            n = int(state[q, 0])
+            fh_h[:, q] = 0; fc_h[:, q] = 0
+            fh_h[0, q, :n, 0] = state[q, 2:2 + n].view(np.int32); fh_h[0, q, :n, 1] = state[q, 2 + depth:2 + depth + n].view(np.int32); fc_h[0, q] = n
+        fh = [B.like_host(fh_h)] * len(sessions); fc = [B.like_host(fc_h)] * len(sessions)
+        B.sync()
+    outs = [B.new((max(nq, 1) * 2 * depth, 3), np.int32) for _ in sessions]
+    B.sync()
+    for s, h, c, o in zip(sessions, fh, fc, outs):
+        s.phase3(W, h, c, o, max_results, enable_coverage)
+    merged = X.allreduce_sum(outs)                                                                             # disjoint Stage-2 rows
+    B.sync()
+    return [s.phase4(m) for s, m in zip(sessions, merged)]
 
 
 class ShardedSearcher:
@@ -208,6 +337,8 @@ class ShardedSearcher:
         self.sess = self.sessions[0]
         self.comm = comm
         self.last = self.sess
+        on_dev = comm.device.type == "cuda" and comm.dist.get_backend() == "nccl"
+        self.X = _DistX(comm, _DevBufs(comm.device) if on_dev else _HostBufs())
 
     def _prefetch(self, s, arena, offs, depth):
         """Sharded planning: this rank runs the expensive index-wide host lookups (LD1 expansion of unknown words, WordMatcher descriptors —
@@ -266,48 +397,8 @@ class ShardedSearcher:
         th.join()
 
     def _finish(self, s, uc, max_results, depth, enable_coverage):
-        import os, time
-        c = self.comm
         self.last = s
-        dbg = os.environ.get("INFX_DEBUG") is not None
-        T = [time.time()]
-        def mark():
-            if dbg: T.append(time.time())
-        guc = c.allreduce_sum_i32(uc) if uc.size else uc                                          # Exchange 1b: df of new fuzzy unions
-        if c.device.type == "cuda" and c.dist.get_backend() == "nccl":
-            # RCCL path: class histograms, hit lists and Stage-2 rows stay in HBM; every collective runs in place on the tensor the kernels wrote
-            torch = c.torch; nq = s.nq
-            counts_t = torch.zeros((max(nq, 1), INFX_NCLASS), dtype=torch.int32, device=c.device)
-            torch.cuda.current_stream().synchronize()
-            mark(); s.phase1_dev(guc, counts_t); mark()
-            c.dist.all_reduce(counts_t, op=c.dist.ReduceOp.SUM)                                   # Exchange 1 (tier decisions need GLOBAL cardinalities, Q11)
-            gcounts = counts_t
-            nd = max(s.nd, 1)
-            hits_t = torch.zeros((nd, depth, 2), dtype=torch.int32, device=c.device); hc_t = torch.zeros(nd, dtype=torch.int32, device=c.device)
-            torch.cuda.current_stream().synchronize()      # the zero fills run on torch's stream, the engine writes on its own: order them
-            mark(); s.phase2_dev(gcounts, hits_t, hc_t); mark()
-            all_hits_t = torch.empty((c.world, nd, depth, 2), dtype=torch.int32, device=c.device)
-            all_hc_t = torch.empty((c.world, nd), dtype=torch.int32, device=c.device)
-            c.dist.all_gather_into_tensor(all_hits_t, hits_t)                                     # Exchange 2 (RCCL all-gather of top-k over xGMI)
-            c.dist.all_gather_into_tensor(all_hc_t, hc_t)
-            outs_t = torch.zeros((max(nq, 1) * 2 * depth, 3), dtype=torch.int32, device=c.device)
-            torch.cuda.current_stream().synchronize()
-            mark(); s.phase3_dev(all_hits_t, all_hc_t, outs_t, max_results, enable_coverage); mark()
-            c.dist.all_reduce(outs_t, op=c.dist.ReduceOp.SUM)                                     # disjoint Stage-2 rows
-            torch.cuda.current_stream().synchronize()
-            mark(); r = s.phase4_dev(outs_t); mark()
-            if dbg and c.rank == 0:
-                import sys
-                print("[infx-shard] ms: allreduce-uc+alloc %.2f phase1 %.2f allreduce-counts(device)+alloc %.2f phase2 %.2f allgather %.2f phase3 %.2f allreduce-rows %.2f phase4 %.2f" % tuple((T[i + 1] - T[i]) * 1e3 for i in range(8)), file=sys.stderr)
-            return r
-        counts = s.phase1(guc)
-        gcounts = c.allreduce_sum_i32(counts) if counts.size else counts                       # Exchange 1
-        hits, hc = s.phase2(gcounts)
-        all_hits = c.allgather(hits) if hits.size else hits.reshape((c.world,) + hits.shape)      # Exchange 2 (all-gather of top-k)
-        all_hc = c.allgather(hc) if hc.size else hc.reshape((c.world,) + hc.shape)
-        outs = s.phase3(all_hits, all_hc, max_results, enable_coverage)
-        merged = c.allreduce_sum_i32(outs) if outs.size else outs                              # disjoint Stage-2 records
-        return s.phase4(merged)
+        return _run_batch([s], self.X, [uc], max_results, depth, enable_coverage)[0]
 
     def last_timings(self):
         return self.last.s.last_timings()
@@ -316,38 +407,12 @@ class ShardedSearcher:
 def simulate_shards_dev(sessions: Sequence[ShardSession], arena, offs, max_results=10, depth=500, enable_coverage=True, device="cuda:0"):
     """simulate_shards with the exchange buffers as torch CUDA tensors (the RCCL code path minus the collectives, which are
     replaced by torch.stack / sum on the same device)."""
-    import torch
     ucs = [s.phase0(arena, offs, depth) for s in sessions]
-    guc = np.sum(np.stack(ucs).astype(np.uint64), axis=0).astype(np.uint32) if ucs[0].size else ucs[0]
-    counts = [s.phase1(guc) for s in sessions]
-    g = np.sum(np.stack(counts).astype(np.uint64), axis=0).astype(np.uint32)
-    nd = max(sessions[0].nd, 1); nq = sessions[0].nq
-    hits, hcs = [], []
-    for s in sessions:
-        h = torch.zeros((nd, depth, 2), dtype=torch.int32, device=device); c = torch.zeros(nd, dtype=torch.int32, device=device)
-        torch.cuda.synchronize()                            # zero fills (torch stream) before the engine's writes (its own stream)
-        s.phase2_dev(g, h, c); hits.append(h); hcs.append(c)
-    all_hits = torch.stack(hits).contiguous(); all_hc = torch.stack(hcs).contiguous()
-    outs = []
-    for s in sessions:
-        o = torch.zeros((max(nq, 1) * 2 * depth, 3), dtype=torch.int32, device=device)
-        torch.cuda.synchronize()
-        s.phase3_dev(all_hits, all_hc, o, max_results, enable_coverage); outs.append(o)
-    merged = torch.stack(outs).sum(dim=0, dtype=torch.int32).contiguous()
-    torch.cuda.synchronize()
-    return [s.phase4_dev(merged) for s in sessions]
+    return _run_batch(sessions, _LocalX(len(sessions), _DevBufs(device)), ucs, max_results, depth, enable_coverage)
 
 
 def simulate_shards(sessions: Sequence[ShardSession], arena, offs, max_results=10, depth=500, enable_coverage=True):
     """Single-process lock-step simulation of W shards (e.g. W engines on ONE GPU): same phases, numpy instead of RCCL.
-    Used by the GPU parity test to check that the sharded path reproduces the unsharded results."""
+    Used by the GPU parity tests to check the sharded path against the oracle."""
     ucs = [s.phase0(arena, offs, depth) for s in sessions]
-    guc = np.sum(np.stack(ucs).astype(np.uint64), axis=0).astype(np.uint32) if ucs[0].size else ucs[0]
-    counts = [s.phase1(guc) for s in sessions]
-    g = np.sum(np.stack(counts).astype(np.uint64), axis=0).astype(np.uint32)
-    ph2 = [s.phase2(g) for s in sessions]
-    all_hits = np.stack([h for h, _ in ph2]); all_hc = np.stack([c for _, c in ph2])
-    outs = [s.phase3(all_hits, all_hc, max_results, enable_coverage) for s in sessions]
-    merged = np.sum(np.stack(outs).astype(np.int64), axis=0).astype(np.int32) if outs[0].size else outs[0]
-    res = [s.phase4(merged) for s in sessions]
-    return res
+    return _run_batch(sessions, _LocalX(len(sessions), _HostBufs()), ucs, max_results, depth, enable_coverage)

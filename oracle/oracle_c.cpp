@@ -271,6 +271,7 @@ int32_t orc_delete_keys(void* h, const int64_t* keys, int64_t n) {
     H->filterCount.clear();      // a Filter object parsed after the deletion counts again (NumberOfDocumentsInFilter lives on the Filter instance, Api/Filter.cs:17)
     return c;
 }
+void orc_restore_all(void* h) { Handle* H = (Handle*)h; H->eng.ix.deleted.clear(); H->filterCount.clear(); }     // clears every Deleted flag (test fixture reuse)
 // One column of non-indexed document fields, by internal doc id. kind: 1 int64 (vals_i), 2 double (vals_d), 3 string (arena + offs, UTF-8)
 void orc_set_column(void* h, const char* name, int32_t kind, int32_t facetable, int64_t n, const int64_t* vals_i, const double* vals_d, const char* arena, const uint64_t* offs) {
     Handle* H = (Handle*)h; Column c; c.name = name; c.facetable = facetable != 0; c.vals.resize((size_t)n);

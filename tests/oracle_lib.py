@@ -314,6 +314,12 @@ def _oe_delete_keys(self, keys):
     return int(self.L.orc_delete_keys(self.h, _p(k, C.c_int64), C.c_int64(len(k))))
 
 
+def _oe_restore_all(self):
+    self.L.orc_restore_all.argtypes = [C.c_void_p]; self.L.orc_restore_all.restype = None
+    self.L.orc_restore_all(self.h)
+
+
 OracleEngine.delete_keys = _oe_delete_keys
+OracleEngine.restore_all = _oe_restore_all
 OracleEngine.set_column = _oe_set_column
 OracleEngine.search_filtered = _oe_search_filtered

@@ -37,3 +37,27 @@ def classify(engine, oracle, queries, k, depth=500):
     finally:
         engine.set_introspection(False)
     return out
+
+
+FINAL_SCORE_TOL = 2.0 ** -6 + 1e-6     # fp32 quantisation of (float)precedence + semantic once precedence >= 2^17 (FusionScorer.cs:218)
+
+
+def assert_final_rows_match_oracle(keys, scores, counts, oracle, texts, k, depth=500, what=""):
+    """Final rows of a product batch against the oracle, query by query: identical DocumentId SETS; identical ORDER unless the rows that moved are
+    2^-6 near-ties — every document's score must then lie within FINAL_SCORE_TOL of the oracle's score for it (an order flip between rows whose
+    scores differ by more than the quantisation step fails).  Returns (identical order, classified flips)."""
+    same = flips = 0
+    for i, q in enumerate(texts):
+        r = oracle.search(q, k, depth)
+        got = keys[i, :int(counts[i])].tolist()
+        assert set(got) == set(r["keys"]), (what, q, got, r["keys"])
+        gs = dict(zip(got, scores[i, :len(got)].tolist())); os_ = dict(zip(r["keys"], r["scores"]))
+        assert all(abs(gs[d] - os_[d]) <= FINAL_SCORE_TOL for d in got), (what, q, gs, os_)
+        if got == r["keys"]:
+            same += 1
+            continue
+        flips += 1
+        for pos, (a, b) in enumerate(zip(got, r["keys"])):       # a flipped position holds two documents whose oracle scores are one quantisation step apart at most
+            if a != b:
+                assert abs(os_[a] - os_[b]) <= FINAL_SCORE_TOL, (what, q, pos, a, b, os_[a], os_[b])
+    return same, flips

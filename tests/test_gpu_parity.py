@@ -174,30 +174,77 @@ def test_batching_is_transparent(synth_pair):
         assert [r.score for r in x.records] == [r.score for r in y.records]   # deterministic, batch-independent
 
 
-def test_sharded_equals_unsharded():
-    """Two doc-range shards (simulated on one GPU, numpy in place of RCCL) reproduce the single-index results exactly:
-    global statistics + count all-reduce + top-k all-gather + owner-scored Stage 2."""
-    from infidex_amd.sharded import create_sharded_engine, ShardSession, simulate_shards
+def test_sharded_equals_the_oracle():
+    """Three doc-range shards (whole 65 536-id containers each; simulated on one GPU, numpy / torch ops in place of RCCL) against the ORACLE:
+    global statistics + count all-reduce + first-pass lists + the exact Stage-1 replay across shards + owner-scored Stage 2.
+    Host exchange buffers and device tensors (the RCCL code path) must agree bit for bit."""
+    from infidex_amd.sharded import create_sharded_engine, ShardSession, simulate_shards, simulate_shards_dev
     from infidex_amd.engine import pack_texts
-    s = Synth(2, docs=30000)
+    from tests.parity_classify import assert_final_rows_match_oracle
+    s = Synth(2, docs=180000)
     arena, offs = s.docs()
-    ref = SearchEngine.create_default(device=0, exact_replay=False); ref.index_flat(None, arena, offs, s.field_weights)   # shards cut ties by (score, doc id)
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
     W = 3
     engs = [create_sharded_engine(r, W, 0) for r in range(W)]
     for e in engs:
         e.index_flat(None, arena, offs, s.field_weights)
+    bases = [e.shard_info() for e in engs]
+    assert [b for b, _ in bases] == [0, 65536, 131072] and sum(n for _, n in bases) == 180000      # container-aligned shards
     sess = [ShardSession(e) for e in engs]
     qa, qo = s.queries(200, qseed=21, fuzz=0.3)
     qs = Synth.texts(qa, qo) + ["qu", "zzzzqq", "the"]
     a2, o2 = pack_texts(qs)
+    host = simulate_shards(sess, a2, o2, 10)
+    dev = simulate_shards_dev(sess, a2, o2, 10)
+    for r in host[1:] + dev:                             # every rank ends with the same rows, whatever memory the exchange buffers live in
+        for x, y in zip(r, host[0]):
+            assert np.array_equal(x, y)
+    k, sc, t, c, f = host[0]
+    same, flips = assert_final_rows_match_oracle(k, sc, c, o, qs, 10, what="3 shards")
+    replays = sum(x.s.last_timings()["exact_replays"] for x in sess)
+    print("sharded vs oracle:", same, "identical order,", flips, "near-tie flips; replayed on their owners:", replays)
+    assert replays > 0                                   # the corpus has ambiguous cuts: the cross-shard replay really ran
+    # the single index gives the same rows (both are the oracle's)
+    ref = SearchEngine.create_default(device=0); ref.index_flat(None, arena, offs, s.field_weights)
     rk, rs, rt, rc, rf = ref.search_packed(a2, o2, 10)
-    from infidex_amd.sharded import simulate_shards_dev
-    res = simulate_shards(sess, a2, o2, 10) + simulate_shards_dev(sess, a2, o2, 10)      # host buffers, then device tensors (RCCL path)
-    for (k, sc, t, c, f) in res:
-        assert np.array_equal(c, rc)
-        assert np.array_equal(k, rk)
-        assert np.array_equal(sc, rs)      # bit-identical scores: same kernels, same arithmetic, only the doc ranges differ
-        assert np.array_equal(t, rt)
+    assert np.array_equal(rc, c)
+    for i in range(len(qs)):
+        assert set(rk[i, :int(rc[i])].tolist()) == set(k[i, :int(c[i])].tolist())
+
+
+def test_sharded_sequential_chain_equals_the_parallel_replay(tmp_path):
+    """INFX_EXACT_SLOW=1 sends every flagged query through the chained k_exact1 (one heap continued from shard to shard) instead of the parallel
+    replay: the rows must be the same, and the oracle's."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np
+from infidex_amd.sharded import create_sharded_engine, ShardSession, simulate_shards
+from infidex_amd.engine import pack_texts
+from tools.synth import Synth
+s = Synth(2, docs=180000); arena, offs = s.docs()
+engs = [create_sharded_engine(r, 2, 0) for r in range(2)]
+for e in engs: e.index_flat(None, arena, offs, s.field_weights)
+qa, qo = s.queries(120, qseed=21, fuzz=0.3)
+a, o = pack_texts(Synth.texts(qa, qo))
+k, sc, t, c, f = simulate_shards([ShardSession(e) for e in engs], a, o, 10)[0]
+np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c)
+'''
+    import os
+    outs = []
+    for slow in ("0", "1"):
+        env = dict(os.environ); env["INFX_EXACT_SLOW"] = slow
+        env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out = str(tmp_path / f"r{slow}.npz")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=900)
+        outs.append(np.load(out))
+    for key in ("k", "sc", "t", "c"):
+        assert np.array_equal(outs[0][key], outs[1][key]), key
+    from tests.parity_classify import assert_final_rows_match_oracle
+    s = Synth(2, docs=180000); arena, offs = s.docs()
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    qa, qo = s.queries(120, qseed=21, fuzz=0.3)
+    assert_final_rows_match_oracle(outs[1]["k"], outs[1]["sc"], outs[1]["c"], o, Synth.texts(qa, qo), 10, what="chained replay")
 
 
 def test_long_documents_take_the_retry_launch():

@@ -32,6 +32,13 @@ def corpus():
     return s, arena, offs, e, Synth.texts(qa, qo)
 
 
+@pytest.fixture(scope="module")
+def oracle(corpus):
+    s, arena, offs, e, texts = corpus
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    return o
+
+
 def run(e, texts, k=K):
     a, o = pack_texts(texts)
     return e.search_packed(a, o, k)
@@ -80,29 +87,42 @@ def test_unpacked_layout_equals_packed(corpus):
         assert np.array_equal(x, y)
 
 
-def test_sharded_equals_single_index_at_scale(corpus):
+def test_sharded_equals_the_oracle_at_scale(corpus, oracle):
+    """Four doc-range shards of the 400k-doc corpus (7 containers: 1 + 2 + 2 + 2) through the RCCL code path (device exchange tensors) against the ORACLE:
+    no query may differ — the exact Stage-1 replay runs across the shards (first-pass lists, global ambiguity test, per-shard chunks, owner-side heap)."""
     from infidex_amd.sharded import create_sharded_engine, ShardSession, simulate_shards_dev
+    from tests.parity_classify import assert_final_rows_match_oracle
     s, arena, offs, e, texts = corpus
     W = 4
     engs = [create_sharded_engine(r, W, 0) for r in range(W)]
     for g in engs:
         g.index_flat(None, arena, offs, s.field_weights)
+    assert all(g.shard_info()[0] % 65536 == 0 and g.shard_info()[1] > 0 for g in engs)
     sess = [ShardSession(g) for g in engs]
     a2, o2 = pack_texts(texts[:500])
-    u = SearchEngine.create_default(device=0, exact_replay=False)      # shards cut Stage-1 ties by (score, doc id): compare like with like
-    u.index_flat(None, arena, offs, s.field_weights)
-    ref = u.search_packed(a2, o2, K)
-    for res in simulate_shards_dev(sess, a2, o2, K):
-        for x, y in zip(res, ref):
+    res = simulate_shards_dev(sess, a2, o2, K)
+    for r in res[1:]:
+        for x, y in zip(r, res[0]):
             assert np.array_equal(x, y)
+    keys, scores, ties, counts, flags = res[0]
+    sample = list(range(0, 500, 3))
+    same, flips = assert_final_rows_match_oracle(keys[sample], scores[sample], counts[sample], oracle, [texts[i] for i in sample], K, what="4 shards at 400k docs")
+    replays = sum(x.s.last_timings()["exact_replays"] for x in sess)
+    print("4 shards vs oracle:", same, "identical order,", flips, "near-tie flips of", len(sample), "; queries replayed on their owners:", replays)
+    assert replays > 0
+    # and the single index returns the same sets for the whole batch (both are the reference's)
+    ref = e.search_packed(a2, o2, K)
+    assert np.array_equal(ref[3], counts)
+    for i in range(500):
+        assert set(ref[0][i, :int(counts[i])].tolist()) == set(keys[i, :int(counts[i])].tolist()), texts[i]
 
 
-def test_oracle_sample_at_scale(corpus):
+def test_oracle_sample_at_scale(corpus, oracle):
     """Final top-k sets AND order vs the oracle at 400k docs.  With the exact Stage-1 replay (k_exact1) no query may differ; should one
     differ it is classified (tests/parity_classify.py) and anything that is not a cut-off tie fails with its dump."""
     from tests.parity_classify import classify
     s, arena, offs, e, texts = corpus
-    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    o = oracle
     sample = texts[:160]
     keys, scores, ties, counts, flags = run(e, sample)
     differ, order_differ = [], 0
@@ -127,7 +147,8 @@ def test_oracle_sample_at_scale(corpus):
 
 
 def test_exact_replay_off_keeps_doc_order_ties(corpus):
-    """exact_replay=False (what document shards run): the cut is taken by (score, doc id); still deterministic and within the tie rule."""
+    """exact_replay=False (INFX_CFG_NO_EXACT_REPLAY, a measurement switch — no product path runs without the replay): the cut is taken by (score, doc id);
+    still deterministic and within the tie rule."""
     s, arena, offs, e, texts = corpus
     u = SearchEngine.create_default(device=0, exact_replay=False)
     u.index_flat(None, arena, offs, s.field_weights)
@@ -141,10 +162,10 @@ def test_exact_replay_off_keeps_doc_order_ties(corpus):
     assert same >= 285
 
 
-def test_deleted_documents_at_scale(corpus):
+def test_deleted_documents_at_scale(corpus, oracle):
     """Deletions at 400k documents, through the exact Stage-1 replay: a deleted document keeps its position in the reference's chunks and match
     lists (so the Vector256 / scalar-tail split of its neighbours is unchanged) but never reaches the heap.  Oracle sample must be identical;
-    the document-sharded pipeline with the same deletions must equal the single index (doc-order ties on both sides)."""
+    the document-sharded pipeline with the same deletions must give the oracle's rows as well."""
     from infidex_amd.sharded import create_sharded_engine, ShardSession, simulate_shards_dev
     s, arena, offs, e, texts = corpus
     rng = np.random.default_rng(77)
@@ -154,7 +175,7 @@ def test_deleted_documents_at_scale(corpus):
     for i in range(len(sample)):
         gone.update(keys0[i, :min(3, int(counts0[i]))].tolist())                    # and the best rows of every sampled query
     gone = np.asarray(sorted(gone), np.int64)
-    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    o = oracle
     try:
         assert e.delete_documents(gone) == len(gone) and o.delete_keys(gone) == len(gone)
         keys, scores, ties, counts, flags = run(e, sample)
@@ -168,18 +189,20 @@ def test_deleted_documents_at_scale(corpus):
                 differ += 1; print("differs:", q, got, r["keys"])
         print("deleted sample:", len(sample) - differ, "identical of", len(sample), "; exact replays", replays)
         assert differ == 0
-        # shards: same deletions on every rank
+        # shards: same deletions on every rank; the cross-shard replay must give the oracle's rows too
+        from tests.parity_classify import assert_final_rows_match_oracle
         W = 2
         engs = [create_sharded_engine(r, W, 0) for r in range(W)]
         for g in engs:
             g.index_flat(None, arena, offs, s.field_weights); g.delete_documents(gone)
-        u = SearchEngine.create_default(device=0, exact_replay=False); u.index_flat(None, arena, offs, s.field_weights); u.delete_documents(gone)
-        a2, o2 = pack_texts(texts[:300]); ref = u.search_packed(a2, o2, K)
-        for res in simulate_shards_dev([ShardSession(g) for g in engs], a2, o2, K):
-            for x, y in zip(res, ref):
-                assert np.array_equal(x, y)
+        a2, o2 = pack_texts(sample)
+        res = simulate_shards_dev([ShardSession(g) for g in engs], a2, o2, K)
+        for x, y in zip(res[0], res[1]):
+            assert np.array_equal(x, y)
+        assert_final_rows_match_oracle(res[0][0], res[0][1], res[0][3], o, sample, K, what="2 shards with deletions")
     finally:
         e.restore_documents()
+        o.restore_all()
 
 
 def test_host_phase_implementation_equals_device_pipeline(tmp_path):

@@ -125,3 +125,81 @@ def test_sharded_planning_exchange_world2():
     assert pend0 > 0 and pend1 > 0                                # WordMatcher descriptor sets of the peer's queries wait for phase 0
     assert bad0 != 0 and bad1 != 0
     assert len(mine0) > 1000 and len(mine1) > 1000
+
+
+class _FakeSession:
+    """Stands in for a ShardSession in the chained replay: continues the state as rank r would (state[q] = state[q] * 10 + r + 1 for needed q)."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def phase2d(self, need, state):
+        for q in range(len(need)):
+            if need[q]:
+                state[q, 0] = state[q, 0] * 10 + self.rank + 1
+
+
+def _distx_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from infidex_amd.sharded import TorchComm, _DistX, _HostBufs
+    X = _DistX(TorchComm(dist), _HostBufs())
+    hits = np.full((3, 4, 2), rank + 1, np.int32)
+    g = X.allgather([hits])[0]
+    nxt = np.asarray([0.5 + rank, 0.0, 2.0], np.float32)
+    gn = X.allgather([nxt])[0]
+    m = X.max_int([100 + 37 * rank])
+    blob = np.full(16, 7 + rank, np.uint8)
+    gb = X.allgather([blob])[0]
+    cnt = np.full((2, 136), rank + 1, np.int32)
+    gc = X.allreduce_sum([cnt])[0]
+    uc = np.asarray([3 + rank, 5], np.uint32)
+    guc = X.allreduce_sum([uc])[0]
+    # the sequential chain: rank 0's step, then rank 1's, on the queries that need it; every rank ends with the last shard's state
+    state = X.chain([_FakeSession(rank)], np.asarray([1, 0, 1], np.uint32), np.zeros((3, 6), np.uint32))
+    q.put((rank, g, gn, m, gb, gc, guc, state))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_object_of_the_sharded_driver_world2():
+    """The collectives _run_batch issues (infidex_amd/sharded.py), through the real-rank exchange object on gloo: shapes, rank order, the padded-size
+    maximum, and the order of the chained sequential replay."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_distx_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+    for rank, g, gn, m, gb, gc, guc, state in got:
+        assert g.shape == (2, 3, 4, 2) and (g[0] == 1).all() and (g[1] == 2).all()
+        assert gn.dtype == np.float32 and gn[:, 0].tolist() == [0.5, 1.5]
+        assert m == 137
+        assert gb.shape == (2, 16) and gb[0, 0] == 7 and gb[1, 0] == 8
+        assert (gc == 3).all() and gc.dtype == np.int32
+        assert guc.tolist() == [7, 10] and guc.dtype == np.uint32
+        assert state[:, 0].tolist() == [12, 0, 12]            # rank 0 first, then rank 1
+
+
+def test_shards_are_whole_containers():
+    """Shard boundaries are multiples of 65 536 documents (whole Roaring containers, Bm25Scorer.cs:195-280 chunks never straddle shards); shards
+    cover the corpus; more shards than containers leaves the last ones empty."""
+    from infidex_amd.sharded import create_sharded_engine
+    from tools.synth import Synth
+    s = Synth(2, docs=150000); arena, offs = s.docs()
+    for W in (1, 2, 3, 5):
+        spans = []
+        for r in range(W):
+            e = create_sharded_engine(r, W, -1); e.index_flat(None, arena, offs, s.field_weights)
+            spans.append(e.shard_info())
+        assert spans[0][0] == 0 and sum(n for _, n in spans) == 150000
+        for (b, n), (b2, _) in zip(spans, spans[1:]):
+            assert b + n == b2
+        assert all(b % 65536 == 0 or b == 150000 for b, _ in spans), spans
+        if W == 5:
+            assert sum(1 for _, n in spans if n == 0) == 2
