@@ -159,6 +159,7 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 }
 
 #include "stage1.hip.inc"
+#include "stage1b.hip.inc"
 #include "exact1.hip.inc"
 #include "exact3.hip.inc"
 #include "exactsh.hip.inc"
@@ -396,7 +397,30 @@ template <int R> static bool acc_lds_layout_ok() {
     }();
     return ok;
 }
-template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp) {
+template <int R, int MW, int CAP> static bool acc2_launch(infx_stream* s, uint32_t nq, Arena ar, int useGrp) {
+    static const bool ok = [] { hipFuncAttributes a{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate2<R, MW, CAP>) == hipSuccess && a.sharedSizeBytes == 0; }();
+    if (!ok) return false;                                   // LDS8 / LDS32 address the dynamic block from LDS address 0: no static __shared__ allowed
+    const int stripe = acc_stripe();
+    static const int dbg = [] { const char* e = getenv("INFX_ACC_DBG"); return e ? atoi(e) : 0; }();      // kernel ablation for profiling only (results are then meaningless)
+    const size_t offBits = ((size_t)R + 64 + (size_t)(CAP + 1) * (MW * 8) + (size_t)(CAP + 1) * 4 + 15) & ~(size_t)15;
+    const size_t lds = offBits + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + CAP * 2;
+    const uint64_t blocks = (uint64_t)nq * ((s->ix->d.nRanges + stripe - 1) / stripe);
+    k_accumulate2<R, MW, CAP><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
+                                                                                (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, dbg);
+    return true;
+}
+// k_accumulate2 (stage1b.hip.inc, the "mask scatter" design) is a measured alternative, bit-identical to k_accumulate but slower on the 10 M-doc batch
+// (10.7 vs 7.5 ms, profiles/r03_accumulate2.md): it runs only with INFX_ACC_V2=1 (A/B parity test, profiling) and for batches of <= 64-term queries
+static bool acc_v1_forced() { static const bool v = [] { const char* e = getenv("INFX_ACC_V2"); return !(e && e[0] == '1'); }(); return v; }
+static int acc2_cap() { static const int v = [] { const char* e = getenv("INFX_ACC2_CAP"); const int x = e ? atoi(e) : 0; return x == 64 ? 64 : 128; }(); return v; }
+template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp, int maxRef) {
+    if (maxRef <= 64 && !acc_v1_forced()) {
+        bool ok;
+        if (acc2_cap() == 64) ok = maxRef <= 32 ? acc2_launch<R, 1, 64>(s, nq, ar, useGrp) : acc2_launch<R, 2, 64>(s, nq, ar, useGrp);
+        else ok = maxRef <= 32 ? acc2_launch<R, 1, 128>(s, nq, ar, useGrp) : acc2_launch<R, 2, 128>(s, nq, ar, useGrp);
+        if (!ok) s->accLayoutBad = true;
+        return;
+    }
     if (!acc_lds_layout_ok<R>()) { s->accLayoutBad = true; return; }
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
     const int stripe = acc_stripe();
@@ -795,12 +819,12 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     Arena ar = make_arena(s);
     HIPCHK(hipEventRecord(s->evA0, s->st));
     switch (ix->d.R) {
-        case 512: launch_acc<512>(s, nq, ar, maxT, useGrp); break;
-        case 1024: launch_acc<1024>(s, nq, ar, maxT, useGrp); break;
-        case 2048: launch_acc<2048>(s, nq, ar, maxT, useGrp); break;
-        case 4096: launch_acc<4096>(s, nq, ar, maxT, useGrp); break;
-        case 8192: launch_acc<8192>(s, nq, ar, maxT, useGrp); break;
-        default: launch_acc<16384>(s, nq, ar, maxT, useGrp); break;
+        case 512: launch_acc<512>(s, nq, ar, maxT, useGrp, maxRef); break;
+        case 1024: launch_acc<1024>(s, nq, ar, maxT, useGrp, maxRef); break;
+        case 2048: launch_acc<2048>(s, nq, ar, maxT, useGrp, maxRef); break;
+        case 4096: launch_acc<4096>(s, nq, ar, maxT, useGrp, maxRef); break;
+        case 8192: launch_acc<8192>(s, nq, ar, maxT, useGrp, maxRef); break;
+        default: launch_acc<16384>(s, nq, ar, maxT, useGrp, maxRef); break;
     }
     if (s->accLayoutBad) return fail(INFX_EHIP, "k_accumulate was built with static LDS: its byte addressing (LDS8) is invalid%s");
     HIPCHK(hipGetLastError());

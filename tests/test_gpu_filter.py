@@ -90,3 +90,26 @@ def test_in_filter_count_follows_deletions():
     assert e.search(Query("alpha", 10, filter="tag = 'x'")).total_in_filter == 0
     e.set_column("tag", ["x", "y"] * 4)
     assert e.search(Query("alpha", 10, filter="tag = 'x'")).total_in_filter == 4
+
+
+def test_book_library_cases_of_the_reference():
+    """FacetingTests.cs:108-560 through the device: the reference's own assertions (tests/book_library.py) on the product's rows and facets, and row for
+    row / facet for facet equality with the oracle — multi-field documents, a string column compared numerically (year >= '2000'), OR / IN / nested
+    filters, NumberOfDocumentsInFilter."""
+    from infidex_amd.engine import Field
+    from tests import book_library as BL
+    from tests.test_oracle_filter_kats import _oracle_books
+    keys, texts, cols = BL.book_fields()
+    e = SearchEngine.create_default(device=0)
+    e.index_documents([Document(k, [Field(n, t, w) for n, t, w in zip(("title", "author", "genre", "description"), ts, BL.BOOK_WEIGHTS)]) for k, ts in zip(keys, texts)])
+    for name, (vals, fac) in cols.items():
+        e.set_column(name, vals, facetable=fac)
+    o = _oracle_books()
+    for case in BL.CASES:
+        name, _, query, k, flt, *_ = case
+        r = e.search(Query(query, k, filter=flt, enable_facets=True))
+        got = [x.document_id for x in r.records]
+        BL.check_case(case, got, r.facets)
+        w = o.search_filtered(query, k, filter=flt, enable_facets=True)
+        assert got == w["keys"] and (r.facets or {}) == w["facets"] and r.total_in_filter == w["in_filter"], (name, got, w)
+    assert e.search(Query("magic", 20)).facets is None                                     # Facets_NotReturnedWhenDisabled

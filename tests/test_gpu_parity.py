@@ -399,3 +399,41 @@ def test_high_term_frequencies():
     o = O.OracleEngine.create_default(); o.index(docs)
     st = compare_batch(e, o, ["alpha", "bravo charlie", "delta echo foxtrot", "golf hotel", "alpha alpha", "hotl", "charlie delta"], 10)
     assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0 and st["s1_boundary"] == 0, st
+
+
+def test_accumulate_designs_agree_bit_for_bit(tmp_path):
+    """k_accumulate (tf scatter + probe, the production kernel) and k_accumulate2 (mask scatter, INFX_ACC_V2=1: a measured alternative) are the same
+    arithmetic in the same order: final rows, fp32 scores and the Stage-1 rows (ids and score bits) of a fuzzy batch must be identical, with deletions too."""
+    import os
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np
+from infidex_amd import SearchEngine
+from infidex_amd.engine import pack_texts
+from tools.synth import Synth
+s = Synth(3, docs=60000); arena, offs = s.docs()
+e = SearchEngine.create_default(device=0, want_features=True); e.index_flat(None, arena, offs, s.field_weights)
+qa, qo = s.queries(400, qseed=33, fuzz=0.5)
+texts = Synth.texts(qa, qo) + ["qu", "", "zzzzqq", "the of and"]
+a, o = pack_texts(texts)
+out = {}
+for tag in ("plain", "deleted"):
+    if tag == "deleted": e.delete_documents(np.arange(0, 60000, 7))
+    k, sc, t, c, f = e.search_packed(a, o, 20)
+    s1 = [e.last_stage1(i) for i in range(0, len(texts), 5)]
+    out[tag + "_k"] = k; out[tag + "_sc"] = sc; out[tag + "_t"] = t; out[tag + "_c"] = c; out[tag + "_f"] = f
+    out[tag + "_s1k"] = np.concatenate([x[0] for x in s1]); out[tag + "_s1s"] = np.concatenate([x[1] for x in s1]).view(np.uint32)
+np.savez(sys.argv[1], **out)
+'''
+    res = []
+    for v1 in ("0", "1"):
+        env = dict(os.environ); env["INFX_ACC_V2"] = v1
+        env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out = str(tmp_path / f"acc{v1}.npz")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=900)
+        res.append(np.load(out))
+    assert len(res[0].files) == 14
+    for key in res[0].files:
+        assert np.array_equal(res[0][key], res[1][key]), key
+    assert res[0]["plain_s1k"].size > 1000

@@ -102,3 +102,42 @@ def test_number_of_documents_in_filter_skips_deleted_documents():
     o.delete_keys([3, 8])
     r = o.search_filtered("alpha", 10, filter="year >= 2000")
     assert r["in_filter"] == 4 and not ({3, 8} & set(r["keys"]))
+
+
+def _oracle_books():
+    import numpy as np
+    from tests import book_library as BL
+    keys, texts, cols = BL.book_fields()
+    flat = [t for doc in texts for t in doc]
+    arena = np.concatenate([O.u16(t) for t in flat]); offs = np.zeros(len(flat) + 1, np.uint64); offs[1:] = np.cumsum([len(O.u16(t)) for t in flat])
+    o = O.OracleEngine.create_default(); o.add_flat(np.asarray(keys, np.int64), arena, offs, BL.BOOK_WEIGHTS); o.finalize()
+    for name, (vals, fac) in cols.items():
+        o.set_column(name, vals, facetable=fac)
+    return o
+
+
+def test_book_library_cases_of_the_reference():
+    """FacetingTests.cs:108-560 on the oracle: multi-field documents, Range / Composite / FilterBuilder / FilterParser filters, "every row satisfies the
+    filter", facet fields and keys (tests/book_library.py holds the fixtures and the reference's assertions)."""
+    from tests import book_library as BL
+    o = _oracle_books()
+    for case in BL.CASES:
+        name, _, query, k, flt, *_ = case
+        r = o.search_filtered(query, k, filter=flt, enable_facets=True)
+        BL.check_case(case, r["keys"], r["facets"])
+        if flt:
+            assert r["in_filter"] == sum(1 for b in BL.BY_ID.values() if (case[6] or (lambda x: True))(b)), name      # NumberOfDocumentsInFilter over the whole library
+
+
+def test_product_facets_disabled_and_enabled():
+    """FacetingTests.cs:11-47: no facets unless Query.EnableFacets; with it the facetable field (category) is counted."""
+    import numpy as np
+    from tests import book_library as BL
+    flat = [t for p in BL.PRODUCTS for t in p[1:]]
+    arena = np.concatenate([O.u16(t) for t in flat]); offs = np.zeros(len(flat) + 1, np.uint64); offs[1:] = np.cumsum([len(O.u16(t)) for t in flat])
+    o = O.OracleEngine.create_default(); o.add_flat(np.asarray([p[0] for p in BL.PRODUCTS], np.int64), arena, offs, BL.PRODUCT_WEIGHTS); o.finalize()
+    o.set_column("category", [p[2] for p in BL.PRODUCTS], facetable=True)
+    r = o.search_filtered("laptop", 10, enable_facets=False)
+    assert r["keys"] and r["keys"][0] == 1 and not r["facets"]
+    r = o.search_filtered("laptop", 10, enable_facets=True)
+    assert r["facets"] and dict(r["facets"]["category"]).get("Electronics", 0) >= 1
