@@ -30,6 +30,7 @@ extern "C" {
 #define INFX_EHIP          3   /* HIP runtime error (incl. "no GPU") */
 #define INFX_ECAPACITY     4   /* a per-batch workspace bound would be exceeded; split the batch */
 #define INFX_EUNSUPPORTED  5   /* input outside the supported envelope (e.g. > INFX_MAX_DOC_TOKENS tokens) */
+#define INFX_ENCCL         6   /* RCCL error (or librccl could not be loaded) */
 
 #define INFX_MAX_QUERY_TERMS   128  /* VectorModel.cs:381 rents 128 raw tokens */
 #define INFX_MAX_QUERY_TOKENS  32   /* Stage-2 query words after dedupe */
@@ -85,6 +86,23 @@ int32_t infx_upload_prefix_docsets(infx_index* idx, uint32_t num_sets, const uin
 /* Document-sharded operation: this index holds internal ids [doc_base, doc_base+num_docs) of a corpus
  * of total_docs; corpus statistics passed in queries are global. */
 int32_t infx_set_shard(infx_index* idx, int32_t rank, int32_t nranks, int32_t doc_base, int32_t total_docs);
+
+/* RCCL inside the boundary (infx_set_shard(..., ncclUniqueId)).  Rank 0 creates the 128-byte ncclUniqueId and ships it to every rank
+ * (any transport); every rank then joins the communicator of its index (ncclCommInitRank(nranks, id, rank) on the index's device, after infx_set_shard).
+ * The collectives below are enqueued on the stream's HIP stream over DEVICE buffers — stream-ordered behind the kernels that produced the data and in
+ * front of the ones that consume it, no host synchronisation: count all-reduce (Exchange 1 / 1b), all-gather of the per-shard top-k (Exchange 2).
+ * librccl is loaded with dlopen at the first call: an unsharded deployment does not need it. */
+#define INFX_RCCL_ID_BYTES 128
+int32_t infx_rccl_unique_id(void* id128);
+int32_t infx_set_shard_comm(infx_index* idx, const void* id128);
+int32_t infx_comm_allreduce_sum_u32(infx_stream* s, void* buf /* device, in place */, uint64_t count);
+int32_t infx_comm_allgather(infx_stream* s, const void* send /* device */, void* recv /* device: nranks x bytes_per_rank */, uint64_t bytes_per_rank);
+/* Plumbing for a native host driver of the sharded phases (infidex_engine.h: infx_session_sharded_finish): per-stream device scratch buffers (slot < 16,
+ * grown on demand, valid until the next call with the same slot), copies between host and device memory of either kind, stream synchronisation. */
+int32_t infx_stream_scratch(infx_stream* s, int32_t slot, uint64_t bytes, void** out);
+int32_t infx_stream_copy(infx_stream* s, void* dst, const void* src, uint64_t bytes);      /* stream-ordered; host pointers are staged; call infx_stream_wait before reading a host destination */
+int32_t infx_stream_fill0(infx_stream* s, void* dev, uint64_t bytes);
+int32_t infx_stream_wait(infx_stream* s);
 
 int32_t infx_stream_create(infx_index* idx, infx_stream** out);
 void    infx_stream_destroy(infx_stream* s);

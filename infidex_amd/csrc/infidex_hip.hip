@@ -24,6 +24,8 @@
 #include <vector>
 #include <algorithm>
 #include <mutex>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and enums only: the functions are resolved with dlopen (rccl_api)
 #include "../../include/infidex_hip.h"
 
 #define WAVE 64
@@ -70,6 +72,7 @@ struct infx_index {
     const uint32_t* colCodes[FILT_MAXCOL] = {}; uint32_t colValues[FILT_MAXCOL] = {}; uint32_t colDocs[FILT_MAXCOL] = {}; uint32_t colCap[FILT_MAXCOL] = {};   // device-resident columns (infx_upload_column)
     std::vector<uint64_t> hPsOff;
     int rank = 0, nranks = 1;
+    ncclComm_t comm = nullptr;         // infx_set_shard_comm
 };
 
 template <class Tp> static hipError_t dalloc(infx_index* ix, Tp** p, size_t n) {
@@ -273,6 +276,7 @@ struct infx_stream {
     void *dNext = nullptr, *dPrior = nullptr, *shBlob = nullptr, *dAllBlobs = nullptr, *dAllNext = nullptr, *dChainState = nullptr, *dChainNeed = nullptr;
     size_t capNext = 0, capPrior = 0, capShBlob = 0, capAllBlobs = 0, capAllNext = 0, capChainState = 0, capChainNeed = 0;
     uint32_t shHead[4] = {0, 0, 0, 0}; uint32_t shNd = 0; int shDepth = 0; bool shSelected = false;
+    void* scratch[16] = {}; size_t capScratch[16] = {};      // infx_stream_scratch
 };
 
 static int32_t grow(void** p, size_t* cap, size_t need) {
@@ -494,6 +498,36 @@ static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
     return INFX_OK;
 }
 
+// ---- RCCL (dlopen) ---------------------------------------------------------------------------------------------------------------------------
+struct RcclApi {
+    bool ok = false; const char* why = "";
+    ncclResult_t (*getId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*init)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*allreduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*allgather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*destroy)(ncclComm_t) = nullptr;
+    const char* (*errstr)(ncclResult_t) = nullptr;
+};
+static RcclApi& rccl_api() {
+    static RcclApi a = [] {
+        RcclApi r;
+        // a process that already holds an RCCL (e.g. torch's) keeps using that copy
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { r.why = "librccl.so not found"; return r; }
+        r.getId = (decltype(r.getId))dlsym(h, "ncclGetUniqueId"); r.init = (decltype(r.init))dlsym(h, "ncclCommInitRank");
+        r.allreduce = (decltype(r.allreduce))dlsym(h, "ncclAllReduce"); r.allgather = (decltype(r.allgather))dlsym(h, "ncclAllGather");
+        r.destroy = (decltype(r.destroy))dlsym(h, "ncclCommDestroy"); r.errstr = (decltype(r.errstr))dlsym(h, "ncclGetErrorString");
+        r.ok = r.getId && r.init && r.allreduce && r.allgather && r.destroy && r.errstr;
+        if (!r.ok) r.why = "librccl.so lacks an expected symbol";
+        return r;
+    }();
+    return a;
+}
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(INFX_ENCCL, #x ": %s", rccl_api().errstr(r_)); } while (0)
+
 extern "C" {
 
 const char* infx_last_error(void) { return g_err.c_str(); }
@@ -519,6 +553,7 @@ int32_t infx_create(const infx_config* cfg, infx_index** out) {
 void infx_destroy(infx_index* ix) {
     if (!ix) return;
     hipSetDevice(ix->cfg.device);
+    if (ix->comm && rccl_api().ok) rccl_api().destroy(ix->comm);
     for (void* p : ix->allocs) hipFree(p);
     delete ix;
 }
@@ -671,6 +706,67 @@ int32_t infx_set_shard(infx_index* ix, int32_t rank, int32_t nranks, int32_t doc
     return INFX_OK;
 }
 
+int32_t infx_rccl_unique_id(void* id128) {
+    if (!id128) return fail(INFX_EINVAL, "null argument%s");
+    if (!rccl_api().ok) return fail(INFX_ENCCL, "RCCL unavailable: %s", rccl_api().why);
+    ncclUniqueId id; NCCLCHK(rccl_api().getId(&id));
+    static_assert(sizeof(ncclUniqueId) == INFX_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof id); return INFX_OK;
+}
+int32_t infx_set_shard_comm(infx_index* ix, const void* id128) {
+    if (!ix || !id128) return fail(INFX_EINVAL, "null argument%s");
+    if (!rccl_api().ok) return fail(INFX_ENCCL, "RCCL unavailable: %s", rccl_api().why);
+    if (ix->comm) return fail(INFX_EINVAL, "this index already joined a communicator%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    ncclUniqueId id; std::memcpy(&id, id128, sizeof id);
+    NCCLCHK(rccl_api().init(&ix->comm, ix->nranks, id, ix->rank));
+    return INFX_OK;
+}
+int32_t infx_comm_allreduce_sum_u32(infx_stream* s, void* buf, uint64_t count) {
+    if (!s || (count && !buf)) return fail(INFX_EINVAL, "null argument%s");
+    if (!s->ix->comm) return fail(INFX_EINVAL, "infx_set_shard_comm has not been called%s");
+    if (!count) return INFX_OK;
+    NCCLCHK(rccl_api().allreduce(buf, buf, (size_t)count, ncclUint32, ncclSum, s->ix->comm, s->st)); s->unsynced = true;
+    return INFX_OK;
+}
+int32_t infx_comm_allgather(infx_stream* s, const void* send, void* recv, uint64_t bytes) {
+    if (!s || (bytes && (!send || !recv))) return fail(INFX_EINVAL, "null argument%s");
+    if (!s->ix->comm) return fail(INFX_EINVAL, "infx_set_shard_comm has not been called%s");
+    if (!bytes) return INFX_OK;
+    NCCLCHK(rccl_api().allgather(send, recv, (size_t)bytes, ncclUint8, s->ix->comm, s->st)); s->unsynced = true;
+    return INFX_OK;
+}
+int32_t infx_stream_scratch(infx_stream* s, int32_t slot, uint64_t bytes, void** out) {
+    if (!s || !out || slot < 0 || slot >= 16) return fail(INFX_EINVAL, "bad scratch arguments%s");
+    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    if (bytes > s->capScratch[slot]) {
+        if (s->unsynced) { int32_t rc_ = stream_sync(s); if (rc_) return rc_; }      // work queued on the old buffer
+        GROW(s->scratch[slot], s->capScratch[slot], (size_t)bytes);
+    }
+    *out = s->scratch[slot]; return INFX_OK;
+}
+int32_t infx_stream_copy(infx_stream* s, void* dst, const void* src, uint64_t bytes) {
+    if (!s || (bytes && (!dst || !src))) return fail(INFX_EINVAL, "null argument%s");
+    if (!bytes) return INFX_OK;
+    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    const bool dd = is_device_ptr(dst), sd = is_device_ptr(src);
+    if (dd && sd) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->st)); s->unsynced = true; return INFX_OK; }
+    if (dd) return up(s, dst, src, bytes);
+    if (sd) return down(s, dst, src, bytes);
+    if (s->unsynced) { int32_t rc_ = stream_sync(s); if (rc_) return rc_; }
+    std::memcpy(dst, src, bytes); return INFX_OK;
+}
+int32_t infx_stream_fill0(infx_stream* s, void* dev, uint64_t bytes) {
+    if (!s || (bytes && !dev)) return fail(INFX_EINVAL, "null argument%s");
+    if (bytes) { HIPCHK(hipSetDevice(s->ix->cfg.device)); HIPCHK(hipMemsetAsync(dev, 0, bytes, s->st)); s->unsynced = true; }
+    return INFX_OK;
+}
+int32_t infx_stream_wait(infx_stream* s) {
+    if (!s) return fail(INFX_EINVAL, "null argument%s");
+    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    return stream_sync(s);
+}
+
 int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     if (!ix || !out) return fail(INFX_EINVAL, "null argument%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
@@ -693,6 +789,7 @@ void infx_stream_destroy(infx_stream* s) {
                   s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters,
                   s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed};
     for (void* p : ps) if (p) hipFree(p);
+    for (void* p : s->scratch) if (p) hipFree(p);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
     hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1, s->evP0, s->evP1, s->evF0, s->evF1, s->evX0, s->evX1};

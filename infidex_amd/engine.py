@@ -208,6 +208,24 @@ class SearchEngine:
             arena = b"".join(bs) + b"\0"
             self._check(self.L.infx_engine_add_column(self.h, name.encode(), 3, int(facetable), C.c_int64(n), None, None, C.c_char_p(arena), _p(offs, C.c_uint64)))
 
+    def facets_of(self, sh, nq, i):
+        """Facets of query i of the last batch (nq queries) searched on session handle sh with Query.EnableFacets: {field: [(value, count)]}, counts over
+        the returned rows, (count desc, value asc) — Core/FacetBuilder.cs:19-105."""
+        facets = {}
+        for k in range(self.L.infx_engine_facet_column_count(sh)):
+            col = C.c_int32(0); codes = np.zeros(128, np.uint32); cnts = np.zeros(128, np.uint32)
+            m = self.L.infx_engine_last_facets(sh, nq, i, k, C.byref(col), _p(codes, C.c_uint32), _p(cnts, C.c_uint32), 128)
+            if m < 0:
+                self._check(1)
+            if m > 0:
+                nb = C.create_string_buffer(256); self.L.infx_engine_column_info(self.h, col.value, nb, 256, None, None)
+                vals = []
+                for j in range(m):
+                    vb = C.create_string_buffer(1024); self.L.infx_engine_column_value(self.h, col.value, int(codes[j]), vb, 1024)
+                    vals.append((vb.value.decode(), int(cnts[j])))
+                facets[nb.value.decode()] = vals
+        return facets
+
     def _default_session(self):
         h = C.c_void_p(); self._check(self.L.infx_engine_default_session(self.h, C.byref(h))); return h
 
@@ -220,25 +238,10 @@ class SearchEngine:
             arena, offs = pack_texts(texts)
             keys, scores, ties, counts, flags = (session or self).search_packed(arena, offs, max_results, depth, enable_coverage)
             nq = len(texts)
-            nf = self.L.infx_engine_facet_column_count(sh) if enable_facets else 0
             out = []
             for i in range(nq):
                 recs = [ScoreEntry(float(scores[i, k]), int(keys[i, k]), int(ties[i, k])) for k in range(int(counts[i]))]
-                facets = None
-                if enable_facets:
-                    facets = {}
-                    for k in range(nf):
-                        col = C.c_int32(0); codes = np.zeros(128, np.uint32); cnts = np.zeros(128, np.uint32)
-                        m = self.L.infx_engine_last_facets(sh, nq, i, k, C.byref(col), _p(codes, C.c_uint32), _p(cnts, C.c_uint32), 128)
-                        if m < 0:
-                            self._check(1)
-                        if m > 0:
-                            nb = C.create_string_buffer(256); self.L.infx_engine_column_info(self.h, col.value, nb, 256, None, None)
-                            vals = []
-                            for j in range(m):
-                                vb = C.create_string_buffer(1024); self.L.infx_engine_column_value(self.h, col.value, int(codes[j]), vb, 1024)
-                                vals.append((vb.value.decode(), int(cnts[j])))
-                            facets[nb.value.decode()] = vals
+                facets = self.facets_of(sh, nq, i) if enable_facets else None
                 out.append(Result(recs, bool(flags[i] & 1), bool(flags[i] & 2), bool(flags[i] & 4), bool(flags[i] & 8), facets, int(nin.value)))
             return out
         finally:

@@ -127,6 +127,14 @@ class ShardSession:
         b = np.ascontiguousarray(blob, np.uint8)
         self.e._check(self.L.infx_session_prefetch_import(self.s.h, _p(b, C.c_uint8), C.c_int64(b.size)))
 
+    def set_filter(self, expr=None, enable_facets=False) -> int:
+        """Query.Filter / Query.EnableFacets on this session; returns THIS SHARD's share of Filter.NumberOfDocumentsInFilter (sum over the shards)."""
+        return self.s.set_filter(expr, enable_facets)
+
+    def facets(self, i):
+        """Facets of query i of the last batch (phase 4 ran the post-filter and counted the facet values of the kept rows; identical on every rank)."""
+        return self.e.facets_of(self.s.h, self.nq, i)
+
     def phase0(self, arena, offs, depth):
         nu = C.c_uint32(0)
         self.nq = len(offs) - 1
@@ -396,12 +404,28 @@ class ShardedSearcher:
             yield res
         th.join()
 
+    def set_filter(self, expr=None, enable_facets=False) -> int:
+        """Query.Filter (Infiscript text, None = no filter) and Query.EnableFacets for the following searches (ResultProcessor.ApplyFilter on the merged
+        rows + FacetBuilder, SearchEngine.cs:298-316).  Collective: same call on every rank.  Returns Filter.NumberOfDocumentsInFilter — every rank
+        counts its own documents on the device, the counts are summed."""
+        mine = [s.set_filter(expr, enable_facets) for s in self.sessions][0]
+        self.in_filter = int(self.comm.allreduce_sum_i32(np.asarray([mine], np.uint32))[0]) if self.comm.world > 1 else int(mine)
+        return self.in_filter
+
+    def last_facets(self, i):
+        return self.last.facets(i)
+
     def _finish(self, s, uc, max_results, depth, enable_coverage):
         self.last = s
         return _run_batch([s], self.X, [uc], max_results, depth, enable_coverage)[0]
 
     def last_timings(self):
         return self.last.s.last_timings()
+
+
+def simulate_set_filter(sessions: Sequence[ShardSession], expr=None, enable_facets=False) -> int:
+    """ShardedSearcher.set_filter for the in-process simulation: installs the filter on every shard's session, sums the per-shard counts."""
+    return int(sum(s.set_filter(expr, enable_facets) for s in sessions))
 
 
 def simulate_shards_dev(sessions: Sequence[ShardSession], arena, offs, max_results=10, depth=500, enable_coverage=True, device="cuda:0"):

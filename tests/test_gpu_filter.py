@@ -113,3 +113,37 @@ def test_book_library_cases_of_the_reference():
         w = o.search_filtered(query, k, filter=flt, enable_facets=True)
         assert got == w["keys"] and (r.facets or {}) == w["facets"] and r.total_in_filter == w["in_filter"], (name, got, w)
     assert e.search(Query("magic", 20)).facets is None                                     # Facets_NotReturnedWhenDisabled
+
+
+def test_sharded_filter_and_facets_match_the_oracle():
+    """Config 5 on document shards (SearchEngine.cs:298-316 after the merge): the post-filter and the facet counts run on the merged rows in phase 4 on
+    every rank, Filter.NumberOfDocumentsInFilter is the sum of the shards' device counts.  Rows, counts and facets must be the oracle's."""
+    from infidex_amd.engine import pack_texts
+    from infidex_amd.sharded import create_sharded_engine, ShardSession, simulate_shards_dev, simulate_set_filter
+    n = 150000
+    s = Synth(4, docs=n); arena, offs = s.docs()
+    year, rating, genre = columns(n, seed=9)
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    W = 3
+    engs = [create_sharded_engine(r, W, 0) for r in range(W)]
+    for x in engs + [o]:
+        if x is not o:
+            x.index_flat(None, arena, offs, s.field_weights)
+        x.set_column("year", year, facetable=True); x.set_column("rating", rating, facetable=False); x.set_column("genre", genre, facetable=True)
+    sess = [ShardSession(e) for e in engs]
+    qa, qo = s.queries(80, qseed=77)
+    texts = Synth.texts(qa, qo); a, off = pack_texts(texts)
+    for flt in ["year >= 2000 AND rating > 7.0", "genre IN ('Drama', 'crime') OR year < 1960", None]:
+        nin = simulate_set_filter(sess, flt, True)
+        res = simulate_shards_dev(sess, a, off, 20)
+        for r in res[1:]:
+            for x, y in zip(r, res[0]):
+                assert np.array_equal(x, y)
+        keys, scores, ties, counts, flags = res[0]
+        for i, q in enumerate(texts):
+            w = o.search_filtered(q, 20, filter=flt, enable_facets=True)
+            assert keys[i, :int(counts[i])].tolist() == w["keys"], (flt, q)
+            assert nin == w["in_filter"], (flt, nin, w["in_filter"])
+            for ss in sess:
+                assert (ss.facets(i) or {}) == w["facets"], (flt, q)
+    simulate_set_filter(sess, None, False)

@@ -73,7 +73,7 @@ def compare_batch(e, o, queries, k, depth=500, check_features=True):
     for i in range(len(qo)):
         order.setdefault(int(qo[i]), []).append(i)
     cov_idx = 0
-    stats = dict(n=0, set_mismatch=0, order_mismatch=0, feat_mismatch=0, s1_boundary=0, s1_bitexact=0, max_s1_rel=0.0, max_final_abs=0.0)
+    stats = dict(n=0, set_mismatch=0, order_mismatch=0, order_unclassified=0, feat_mismatch=0, s1_boundary=0, s1_bitexact=0, max_s1_rel=0.0, max_final_abs=0.0)
     for qi, q in enumerate(queries):
         r = o.search(q, k, depth)
         got = res[qi]
@@ -124,14 +124,17 @@ def compare_batch(e, o, queries, k, depth=500, check_features=True):
         gids = [x.document_id for x in got.records]
         if set(gids) != set(r["keys"]):
             stats["set_mismatch"] += 1
-        elif gids != r["keys"]:
-            stats["order_mismatch"] += 1
-        for x, s_or in zip(got.records, r["scores"]):
-            pass
-        if gids == r["keys"]:
-            for x, s_or in zip(got.records, r["scores"]):
-                stats["max_final_abs"] = max(stats["max_final_abs"], abs(x.score - float(s_or)))
-                assert abs(x.score - float(s_or)) <= FINAL_ATOL, (q, x, s_or)
+        else:
+            # every returned document carries the oracle's score for it (to the 2^-6 quantisation of (float)precedence + semantic) ...
+            os_ = dict(zip(r["keys"], [float(v) for v in r["scores"]]))
+            for x in got.records:
+                stats["max_final_abs"] = max(stats["max_final_abs"], abs(x.score - os_[x.document_id]))
+                assert abs(x.score - os_[x.document_id]) <= FINAL_ATOL, (q, x, os_[x.document_id])
+            # ... and an order flip is accepted only between documents whose ORACLE scores are one quantisation step apart at most (classified near-tie)
+            if gids != r["keys"]:
+                stats["order_mismatch"] += 1
+                if any(a != b and abs(os_[a] - os_[b]) > FINAL_ATOL for a, b in zip(gids, r["keys"])):
+                    stats["order_unclassified"] += 1
     return stats
 
 
@@ -160,7 +163,8 @@ def test_synthetic_parity(synth_pair):
     assert st["feat_mismatch"] == 0
     assert st["set_mismatch"] == 0, st      # identical top-k DocumentId sets
     assert st["s1_boundary"] == 0, st       # exact replay: the Stage-1 top-`depth` SET is the oracle's for every query, ties included
-    assert st["order_mismatch"] <= st["n"] * 0.02, st   # order may flip only between 2^-6-quantised near-ties
+    assert st["order_unclassified"] == 0, st                # an order flip is a classified 2^-6 near-tie (compare_batch), never anything else
+    assert st["order_mismatch"] <= st["n"] * 0.02, st
 
 
 def test_batching_is_transparent(synth_pair):

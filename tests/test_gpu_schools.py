@@ -40,4 +40,4 @@ def test_school_queries_match_the_oracle(schools):
     for k in (20, 50):
         st = compare_batch(e, o, qs, k)
         assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, st
-        assert st["order_mismatch"] <= 1, st
+        assert st["order_unclassified"] == 0 and st["order_mismatch"] <= 1, st      # a flip, if any, is a classified 2^-6 near-tie
