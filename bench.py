@@ -43,6 +43,7 @@ def main():
     # measured at 10 M docs (queries/s, p50 / p95 batch latency ms): 4: 53.3 k, 48 / 106; 5: 63.9 k, 60 / 119; 6: 65.9 k, 85 / 126; 7: 66.2 k, 76 / 177; 8: 59.1 k, 86 / 375 —
     # the replay kernels of a batch run one workgroup per flagged query and leave most CUs to other batches' full-width kernels
     ap.add_argument("--sessions", type=int, default=6, help="batches in flight (host threads, one engine session each)")
+    ap.add_argument("--shard-sessions", type=int, default=3, help="sharded runs: batches in flight per rank (pipeline sessions, each with its own stream and communicator)")
     ap.add_argument("--distinct-batches", type=int, default=0, help="distinct synthetic query batches the steps cycle through; 0 (default) = warmup + steps, "
                     "i.e. no batch — and so no misspelt word beyond what the Zipf stream itself repeats — occurs twice: planning is measured cold")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent full-index replicas instead of document shards")
@@ -150,11 +151,10 @@ def main():
     # a shared cursor, so the host-side preparation of one batch overlaps the GPU stages of another.  Every batch still runs the
     # complete hot path; results do not depend on the interleaving (tests/test_gpu_parity.py::test_batching_is_transparent).
     if sharded:
-        searcher = ShardedSearcher(eng, TorchComm(dist))
-        for _ in range(2):                               # both pipeline sessions allocate their workspaces
-            searcher.search_packed(setup_batch[0], setup_batch[1], k, 500)
-        for s in range(args.warmup):
-            searcher.search_packed(batches[s][0], batches[s][1], k, 500)
+        nsess = max(1, min(args.shard_sessions, args.steps))
+        searcher = ShardedSearcher(eng, TorchComm(dist), sessions=nsess)
+        list(searcher.search_stream([setup_batch] * len(searcher.sessions), k, 500))       # every pipeline session allocates its workspaces
+        list(searcher.search_stream(batches[:args.warmup], k, 500))
         sync()
         tim, lat, results = [], [], []
         t_start = time.time()
@@ -163,13 +163,15 @@ def main():
         def lockstep(bs):
             for a_, o_ in bs:
                 t0_ = time.time(); r_ = searcher.search_packed(a_, o_, k, 500); stamps.append((t0_, time.time())); yield r_
-        stream = lockstep(batches[args.warmup:nsteps]) if os.environ.get("INFX_SHARD_LOCKSTEP") == "1" else searcher.search_stream(batches[args.warmup:nsteps], k, 500, stamps=stamps)
+        lock = os.environ.get("INFX_SHARD_LOCKSTEP") == "1"
+        stream = lockstep(batches[args.warmup:nsteps]) if lock else searcher.search_stream(batches[args.warmup:nsteps], k, 500, stamps=stamps, timings=tim)
         for keys, scores, ties, counts, flags in stream:
-            tim.append(searcher.last_timings())
+            if lock:
+                tim.append(searcher.last_timings())
             results.append((keys, counts))
         lat = [(b - a) * 1000.0 for a, b in stamps]
         first_keys = (results[0][0].copy(), results[0][1].copy())
-        nsess = 2
+        nsess = len(searcher.sessions)
         sessions = None
     else:
         nsess = max(1, min(args.sessions, args.steps))

@@ -44,7 +44,7 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
 
 /* out_keys/out_scores/out_ties: nq x max_results (row-major); out_counts: nq; out_flags (may be NULL): bit0 query needs the
  * short-query path or exceeds the Stage-2 query envelope (empty result), bit1 coverage stage ran, bit2 coverage returned nothing -> Stage-1
- * fallback, bit3 at least one candidate document exceeded the Stage-2 envelope (INFX_MAX_DOC_TOKENS tokens) and was left out of the ranking. */
+ * fallback, bit3 a candidate document was left out of the ranking: the batch's over-long documents (> INFX_MAX_DOC_TOKENS words) exceeded the token-table pool. */
 int32_t infx_engine_search_batch(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
                                  int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                  uint32_t* out_counts, uint32_t* out_flags);
@@ -91,6 +91,29 @@ int32_t infx_session_phase2b(infx_session* s, int32_t nranks, const void* all_hi
 int32_t infx_session_phase2b_blob(infx_session* s, void* dst, uint64_t padded_bytes);
 int32_t infx_session_phase2c(infx_session* s, int32_t nranks, const void* all_blobs, uint64_t padded_bytes, void* hits, void* hitcounts);
 int32_t infx_session_phase2d(infx_session* s, const uint32_t* need, void* state);
+/* ---- native driver of the sharded phases -------------------------------------------------------------------------------------------------------------
+ * Everything after phase 0 of a batch — phases 1, 2a-2d, 3, 4 with every collective in between — in ONE call, driven from C++ with no interpreter on the
+ * path.  The collectives come through an infx_comm:
+ *   infx_engine_comm_rccl : RCCL inside the library (infidex_hip.h: infx_set_shard_comm).  Exchange buffers live in HBM, the collectives are enqueued on the
+ *                           session's HIP stream between the kernels that produce and consume them; the host synchronises only where it needs a value
+ *                           (global fuzzy df for idf, the padded blob size, the "needs the sequential chain" flags).
+ *   caller-supplied ops   : any other transport (the tests pass torch.distributed/gloo callbacks; device_buffers = 0: host exchange buffers).
+ * Results are those of the phase-by-phase API (infidex_amd/sharded.py drives either). */
+typedef struct infx_comm {
+    void*   ctx;
+    int32_t rank, nranks;
+    int32_t device_buffers;      /* 1: buffers handed to the ops are device memory and the ops are stream-ordered on `stream`; 0: host memory, blocking ops */
+    int32_t reserved;
+    int32_t (*allreduce_sum_u32)(void* ctx, void* buf, uint64_t count, void* stream);                       /* in place */
+    int32_t (*allgather)(void* ctx, const void* send, void* recv, uint64_t bytes_per_rank, void* stream);   /* recv: nranks x bytes_per_rank */
+} infx_comm;
+int32_t infx_engine_rccl_unique_id(void* id128);                                  /* rank 0: 128 bytes to ship to every rank */
+int32_t infx_engine_comm_rccl(infx_engine* e, const void* id128, infx_comm* out);  /* every rank, after infx_engine_index_documents */
+int32_t infx_session_comm_rccl(infx_session* s, const void* id128, infx_comm* out); /* a communicator per session: several batches in flight per rank */
+/* phase 0 first (infx_session_phase0, possibly on a planner thread); then this call, in the same order on every rank */
+int32_t infx_session_sharded_finish(infx_session* s, const infx_comm* comm, int32_t max_results, int32_t enable_coverage,
+                                    int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags);
+
 int32_t infx_session_phase3(infx_session* s, int32_t nranks, const infx_hit* all_hits, const uint32_t* all_hitcounts, int32_t max_results,
                             int32_t enable_coverage, uint64_t* ncand);
 int32_t infx_session_outs(infx_session* s, int32_t* outs3);
@@ -132,6 +155,13 @@ int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* doc
  * (Bm25Scorer.cs:322-323,455-459,622-624; SearchPipeline.cs:404-406,463-465,532-537).  Exclusive — no search in flight (the reference's write
  * lock).  On a sharded engine every rank must make the same call.  *out_marked (optional) = documents newly marked. */
 int32_t infx_engine_delete_documents(infx_engine* e, const int64_t* keys, int64_t n, int64_t* out_marked);
+/* SearchEngine.Load (SearchEngine.cs:399-441) of an INFDX2 file written by SearchEngine.Save (Indexing/IndexPersistence.cs:33-99): header and data
+ * checksums are verified, the documents { DocumentKey, IndexedText as the single Med-weight field "content", Deleted } are indexed and uploaded like
+ * infx_engine_index_documents does, and every stored term (text, document frequency, postings with their weight bytes) is compared with the index
+ * just built; the file's derived sections (FST, short-query index, metadata cache, WordMatcher) are rebuilt from the documents, not read.
+ * checked3 (optional): documents, stored terms compared, stored postings compared.  INFX_EUNSUPPORTED when the stored postings are not what the
+ * builder produces for the stored texts (e.g. written from differently weighted fields); INFX_EINVAL for a foreign or corrupted file. */
+int32_t infx_engine_load_index(infx_engine* e, const char* path, int64_t* checked3);
 int32_t infx_engine_restore_documents(infx_engine* e);      /* clears every Deleted flag */
 
 /* ---- Query.Filter (Infiscript, Api/FilterParser.cs) and Query.EnableFacets (config 5) -------------------------------------------------

@@ -34,8 +34,9 @@ extern "C" {
 
 #define INFX_MAX_QUERY_TERMS   128  /* VectorModel.cs:381 rents 128 raw tokens */
 #define INFX_MAX_QUERY_TOKENS  32   /* Stage-2 query words after dedupe */
-#define INFX_MAX_QUERY_CHARS   256
-#define INFX_MAX_DOC_TOKENS    192  /* Stage-2 words per document text */
+#define INFX_MAX_QUERY_CHARS   512
+#define INFX_MAX_DOC_TOKENS    192  /* Stage-2 words per document text handled in registers / scratch; longer texts (the reference allows 65 535 characters,
+                                       Api/DocumentFields.cs:140) take k_stage2's global-workspace pass: slower, same results */
 #define INFX_NFEAT             32   /* ints per infx_cov_out.feat */
 
 typedef struct infx_index infx_index;     /* device-resident immutable index (one shard) */
@@ -95,6 +96,9 @@ int32_t infx_set_shard(infx_index* idx, int32_t rank, int32_t nranks, int32_t do
 #define INFX_RCCL_ID_BYTES 128
 int32_t infx_rccl_unique_id(void* id128);
 int32_t infx_set_shard_comm(infx_index* idx, const void* id128);
+/* a communicator of its own for one stream (another ncclUniqueId; same call order on every rank): batches in flight on different streams then exchange
+ * without serialising on one communicator.  A stream without one uses the index's. */
+int32_t infx_stream_comm(infx_stream* s, const void* id128);
 int32_t infx_comm_allreduce_sum_u32(infx_stream* s, void* buf /* device, in place */, uint64_t count);
 int32_t infx_comm_allgather(infx_stream* s, const void* send /* device */, void* recv /* device: nranks x bytes_per_rank */, uint64_t bytes_per_rank);
 /* Plumbing for a native host driver of the sharded phases (infidex_engine.h: infx_session_sharded_finish): per-stream device scratch buffers (slot < 16,
@@ -198,7 +202,7 @@ typedef struct infx_cov_out {
     uint8_t tiebreaker;
     uint8_t word_hits;     /* min(WordHits,255) */
     uint8_t lcs;           /* min(lcs,255) when want_lcs */
-    uint8_t status;        /* 0 ok, INFX_EUNSUPPORTED when the text exceeds INFX_MAX_DOC_TOKENS */
+    uint8_t status;        /* 0 ok; INFX_EUNSUPPORTED: the over-long documents (> INFX_MAX_DOC_TOKENS words) of one launch exceeded the 64 MB token-table pool */
     int32_t word_hits_full;
 } infx_cov_out;
 

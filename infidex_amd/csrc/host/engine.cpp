@@ -8,6 +8,7 @@
 //   TopKHeap / ScoreEntry / ConsolidateSegments  Core/TopKHeap.cs, Core/ScoreEntry.cs:25-36, Scoring/SegmentProcessor.cs:15-37
 #include "query.h"
 #include "filter.h"
+#include "infdx2.h"
 #include <mutex>
 #include "../../../include/infidex_engine.h"
 #include <chrono>
@@ -956,6 +957,133 @@ int32_t infx_session_phase2d(infx_session* S, const uint32_t* need, void* state)
     if (rc) { g_eerr = infx_last_error(); return rc; }
     return INFX_OK;
 }
+// ---- native driver of the sharded phases (infidex_engine.h) ---------------------------------------------------------------------------------------------
+namespace {
+int32_t rccl_allreduce(void* ctx, void* buf, uint64_t count, void* /*stream*/) { return infx_comm_allreduce_sum_u32((infx_stream*)ctx, buf, count); }
+int32_t rccl_allgather(void* ctx, const void* send, void* recv, uint64_t bytes, void* /*stream*/) { return infx_comm_allgather((infx_stream*)ctx, send, recv, bytes); }
+// exchange buffers of one batch: HBM scratch of the session's stream (RCCL) or host vectors (other transports)
+struct XBufs {
+    infx_session* S; bool dev; std::vector<std::vector<uint8_t>> host; int slot = 0;
+    XBufs(infx_session* s, bool d) : S(s), dev(d) { host.reserve(16); }
+    int32_t get(size_t bytes, void** out, bool zero) {
+        bytes = std::max<size_t>(bytes, 16);
+        if (dev) { int32_t rc = infx_stream_scratch(S->stream, slot++, bytes, out); if (rc) return rc; return zero ? infx_stream_fill0(S->stream, *out, bytes) : INFX_OK; }
+        host.emplace_back(bytes, (uint8_t)0); *out = host.back().data(); return INFX_OK;
+    }
+};
+}
+int32_t infx_engine_rccl_unique_id(void* id128) { int32_t rc = infx_rccl_unique_id(id128); if (rc) g_eerr = infx_last_error(); return rc; }
+int32_t infx_engine_comm_rccl(infx_engine* e, const void* id128, infx_comm* out) {
+    if (!e || !id128 || !out) return efail(INFX_EINVAL, "null argument");
+    if (!e->dev || !e->indexed) return efail(INFX_EINVAL, "the RCCL communicator is created on an indexed engine with a GPU");
+    int32_t rc = infx_set_shard_comm(e->dev, id128);
+    if (rc) { g_eerr = infx_last_error(); return rc; }
+    std::memset(out, 0, sizeof *out);
+    out->ctx = nullptr;                      // the session's stream is supplied per call (the collective runs on ITS HIP stream)
+    out->rank = e->rank; out->nranks = e->nranks; out->device_buffers = 1;
+    out->allreduce_sum_u32 = rccl_allreduce; out->allgather = rccl_allgather;
+    return INFX_OK;
+}
+int32_t infx_session_comm_rccl(infx_session* S, const void* id128, infx_comm* out) {
+    if (!S || !id128 || !out) return efail(INFX_EINVAL, "null argument");
+    if (!S->stream) return efail(INFX_EINVAL, "the session has no GPU stream");
+    int32_t rc = infx_stream_comm(S->stream, id128);
+    if (rc) { g_eerr = infx_last_error(); return rc; }
+    std::memset(out, 0, sizeof *out);
+    out->rank = S->e->rank; out->nranks = S->e->nranks; out->device_buffers = 1;
+    out->allreduce_sum_u32 = rccl_allreduce; out->allgather = rccl_allgather;
+    return INFX_OK;
+}
+int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int32_t max_results, int32_t enable_coverage,
+                                    int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags) {
+    if (!S || !comm || !comm->allreduce_sum_u32 || !comm->allgather || !out_keys || !out_scores || !out_counts || max_results < 1) return efail(INFX_EINVAL, "bad arguments");
+    infx_engine* e = S->e; Batch& B = *S->batch;
+    if (comm->nranks != e->nranks || comm->rank != e->rank) return efail(INFX_EINVAL, "communicator and engine disagree about the shard layout");
+    const int W = comm->nranks; const bool dev = comm->device_buffers != 0;
+    void* const cctx = comm->ctx ? comm->ctx : (void*)S->stream;       // the in-library RCCL ops run on the session's stream
+    auto chk = [&](int32_t rc) { if (rc && g_eerr.empty()) g_eerr = infx_last_error(); return rc; };
+#define XCHK(x) do { int32_t rc_ = chk(x); if (rc_) return rc_; } while (0)
+    XBufs X(S, dev);
+    const uint32_t nq = B.nq; const int depth = B.depth;
+    // Exchange 1b: global df of the batch's new fuzzy unions (the host needs the values: idf is computed there with the reference's logf)
+    std::vector<uint32_t> guc(B.pendingCounts);
+    if (!guc.empty()) {
+        if (dev) {
+            void* d = nullptr; XCHK(X.get(guc.size() * 4, &d, false));
+            XCHK(infx_stream_copy(S->stream, d, guc.data(), guc.size() * 4));
+            XCHK(comm->allreduce_sum_u32(cctx, d, guc.size(), nullptr));
+            XCHK(infx_stream_copy(S->stream, guc.data(), d, guc.size() * 4)); XCHK(infx_stream_wait(S->stream));
+        } else XCHK(comm->allreduce_sum_u32(cctx, guc.data(), guc.size(), nullptr));
+    }
+    static const uint32_t zero = 0;
+    // phase 1 + Exchange 1: class histograms (tier decisions need GLOBAL cardinalities, Q11)
+    void* counts = nullptr; XCHK(X.get((size_t)std::max<uint32_t>(nq, 1) * INFX_NCLASS * 4, &counts, true));
+    uint32_t nd = 0; XCHK(infx_session_phase1x(S, guc.empty() ? &zero : guc.data(), counts, &nd));
+    XCHK(comm->allreduce_sum_u32(cctx, counts, (uint64_t)std::max<uint32_t>(nq, 1) * INFX_NCLASS, nullptr));
+    // phase 2a + Exchange 2a: first-pass lists, counts, best score left out
+    const size_t ndp = std::max<uint32_t>(nd, 1), hitB = ndp * depth * sizeof(infx_hit);
+    void *hits = nullptr, *hc = nullptr, *nxt = nullptr, *ah = nullptr, *ac = nullptr, *an = nullptr;
+    XCHK(X.get(hitB, &hits, true)); XCHK(X.get(ndp * 4, &hc, true)); XCHK(X.get(ndp * 4, &nxt, true));
+    XCHK(X.get(hitB * W, &ah, false)); XCHK(X.get(ndp * 4 * W, &ac, false)); XCHK(X.get(ndp * 4 * W, &an, false));
+    XCHK(infx_session_phase2a(S, counts, hits, hc, nxt));
+    XCHK(comm->allgather(cctx, hits, ah, hitB, nullptr)); XCHK(comm->allgather(cctx, hc, ac, ndp * 4, nullptr)); XCHK(comm->allgather(cctx, nxt, an, ndp * 4, nullptr));
+    // phase 2b + Exchange 2c: this shard's part of the exact replay, packed; padded to the largest blob of the world
+    uint64_t blobBytes = 0; XCHK(infx_session_phase2b(S, W, ah, ac, an, &blobBytes));
+    uint64_t pad = blobBytes;
+    {   // max over ranks through the sum-all-reduce the communicator has: one slot per rank
+        std::vector<uint32_t> sz((size_t)W, 0u); sz[comm->rank] = (uint32_t)((blobBytes + 15) >> 4);
+        if (dev) {
+            void* d = nullptr; XCHK(X.get(sz.size() * 4, &d, false));
+            XCHK(infx_stream_copy(S->stream, d, sz.data(), sz.size() * 4));
+            XCHK(comm->allreduce_sum_u32(cctx, d, sz.size(), nullptr));
+            XCHK(infx_stream_copy(S->stream, sz.data(), d, sz.size() * 4)); XCHK(infx_stream_wait(S->stream));
+        } else XCHK(comm->allreduce_sum_u32(cctx, sz.data(), sz.size(), nullptr));
+        pad = 16ull * *std::max_element(sz.begin(), sz.end());
+    }
+    void *blob = nullptr, *ab = nullptr; XCHK(X.get(pad, &blob, false)); XCHK(X.get(pad * W, &ab, false));
+    XCHK(infx_session_phase2b_blob(S, blob, pad));
+    XCHK(comm->allgather(cctx, blob, ab, pad, nullptr));
+    // phase 2c + Exchange 2b: owner-side heap; the all-gather of the per-rank final lists
+    XCHK(infx_session_phase2c(S, W, ab, pad, hits, hc));
+    XCHK(comm->allgather(cctx, hits, ah, hitB, nullptr)); XCHK(comm->allgather(cctx, hc, ac, ndp * 4, nullptr));
+    // queries the parallel replay could not certify (rare): the literal sequential replay, shard after shard
+    std::vector<uint32_t> fc((size_t)W * ndp);
+    XCHK(infx_stream_copy(S->stream, fc.data(), ac, fc.size() * 4)); XCHK(infx_stream_wait(S->stream));
+    std::vector<uint32_t> need(ndp, 0u); bool anyNeed = false;
+    for (int w = 0; w < W; w++) for (uint32_t q = 0; q < nd; q++) if (fc[(size_t)w * ndp + q] == 0xFFFFFFFFu) { need[q] = 1; anyNeed = true; }
+    if (anyNeed) {
+        const size_t words = ndp * (2 + 2 * (size_t)depth);
+        std::vector<uint32_t> state(words, 0u), all(words * W);
+        void *ds = nullptr, *da = nullptr;
+        if (dev) { XCHK(X.get(words * 4, &ds, false)); XCHK(X.get(words * 4 * W, &da, false)); }
+        for (int r = 0; r < W; r++) {
+            if (r == comm->rank) XCHK(infx_session_phase2d(S, need.data(), state.data()));
+            if (dev) {
+                XCHK(infx_stream_copy(S->stream, ds, state.data(), words * 4)); XCHK(comm->allgather(cctx, ds, da, words * 4, nullptr));
+                XCHK(infx_stream_copy(S->stream, all.data(), da, words * 4 * W)); XCHK(infx_stream_wait(S->stream));
+            } else XCHK(comm->allgather(cctx, state.data(), all.data(), words * 4, nullptr));
+            std::memcpy(state.data(), all.data() + (size_t)r * words, words * 4);          // rank r's continuation is the state of record
+        }
+        std::vector<infx_hit> fh((size_t)W * ndp * depth);
+        XCHK(infx_stream_copy(S->stream, fh.data(), ah, fh.size() * sizeof(infx_hit))); XCHK(infx_stream_wait(S->stream));
+        for (uint32_t q = 0; q < nd; q++) if (need[q]) {
+            const uint32_t* st = state.data() + (size_t)q * (2 + 2 * (size_t)depth); const uint32_t n = st[0];
+            for (int w = 0; w < W; w++) { fc[(size_t)w * ndp + q] = 0; std::memset(fh.data() + ((size_t)w * ndp + q) * depth, 0, (size_t)depth * sizeof(infx_hit)); }
+            for (uint32_t i = 0; i < n; i++) { infx_hit h; h.doc = (int32_t)st[2 + i]; std::memcpy(&h.score, &st[2 + depth + i], 4); fh[(size_t)q * depth + i] = h; }
+            fc[q] = n;
+        }
+        XCHK(infx_stream_copy(S->stream, ah, fh.data(), fh.size() * sizeof(infx_hit))); XCHK(infx_stream_copy(S->stream, ac, fc.data(), fc.size() * 4));
+        if (dev) XCHK(infx_stream_wait(S->stream));
+    }
+    // phase 3 + the all-reduce of the disjoint Stage-2 rows + phase 4
+    void* outs = nullptr; XCHK(X.get((size_t)std::max<uint32_t>(nq, 1) * 2 * depth * sizeof(infx_cov_out), &outs, true));
+    XCHK(infx_session_phase3x(S, W, ah, ac, max_results, enable_coverage, outs));
+    XCHK(comm->allreduce_sum_u32(cctx, outs, (uint64_t)std::max<uint32_t>(nq, 1) * 2 * depth * 3, nullptr));
+    XCHK(infx_session_phase4(S, (const int32_t*)outs, out_keys, out_scores, out_ties, out_counts, out_flags));
+#undef XCHK
+    return INFX_OK;
+}
+
 int32_t infx_session_phase3(infx_session* S, int32_t W, const infx_hit* all_hits, const uint32_t* all_counts, int32_t max_results, int32_t enable_coverage, uint64_t* ncand) {
     if (!S || W < 1 || max_results < 1) return efail(INFX_EINVAL, "bad arguments");
     static const bool hostPhases = getenv("INFX_PHASED") != nullptr;
@@ -1194,6 +1322,43 @@ int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uin
 // raw access for bench.py (HBM-resident inputs are the engine's; these expose the flat host arrays for oracle adoption)
 int32_t infx_engine_device_handles(infx_engine* e, infx_index** idx, infx_stream** st) { if (!e) return INFX_EINVAL; if (idx) *idx = e->dev; if (st) *st = e->def->stream; return INFX_OK; }
 
+
+// ---- INFDX2 index files (host/infdx2.h) -------------------------------------------------------------------------------------------------------
+// SearchEngine.Load (SearchEngine.cs:399-441) for files whose documents were indexed as single Med-weight fields: the documents are read and indexed
+// (which uploads the shard as infx_engine_index_documents does), Deleted flags are applied, and every stored term is compared with the index just
+// built.  *checked3 = {documents, stored terms compared, stored postings compared}.  INFX_EUNSUPPORTED: the stored postings are not what this
+// builder produces for the stored texts (multi-field weights, other tokenizer settings); INFX_EINVAL: not an INFDX2 file / corrupted.
+int32_t infx_engine_load_index(infx_engine* e, const char* path, int64_t* checked3) {
+    if (!e || !path) return efail(INFX_EINVAL, "null argument");
+    if (e->indexed) return efail(INFX_EINVAL, "this engine instance is already indexed");
+    infdx2::File F;
+    if (!infdx2::read_file(path, F)) return efail(INFX_EINVAL, F.error);
+    const int64_t n = (int64_t)F.docs.size();
+    std::vector<int64_t> keys((size_t)n); std::vector<uint64_t> offs((size_t)n + 1, 0); std::vector<uint16_t> arena;
+    for (int64_t d = 0; d < n; d++) {
+        if (F.docs[d].id != (int32_t)d) return efail(INFX_EUNSUPPORTED, "document ids of the file are not 0..n-1 in order (written after deletions): the stored postings refer to ids Load does not restore");
+        keys[d] = F.docs[d].key; arena.insert(arena.end(), F.docs[d].text.begin(), F.docs[d].text.end()); offs[d + 1] = arena.size();
+    }
+    if (arena.empty()) arena.push_back(0);
+    const int32_t w = 1;      // Weight.Med: ReadDocuments adds the text as the single field "content" with Weight.Med (IndexPersistence.cs:338-339)
+    int32_t rc = infx_engine_index_documents(e, n, keys.data(), arena.data(), offs.data(), 1, &w);
+    if (rc) return rc;
+    const HostIndex& ix = e->ix;
+    int64_t nterms = 0, npost = 0;
+    for (auto& t : F.terms) {
+        const int64_t id = ix.terms.keys.find(uview((const u16*)t.text.data(), t.text.size()));
+        if (id < 0) return efail(INFX_EUNSUPPORTED, "a stored term does not exist in the index built from the stored documents");
+        const uint64_t b = ix.terms.off[id], len = ix.terms.off[id + 1] - b;
+        if (ix.df[id] != t.df || len != t.docs.size()) return efail(INFX_EUNSUPPORTED, "a stored term's document frequency / posting count differs from the rebuilt index");
+        for (size_t i = 0; i < t.docs.size(); i++)
+            if (ix.terms.doc[b + i] != t.docs[i] || ix.terms.w[b + i] != t.w[i]) return efail(INFX_EUNSUPPORTED, "a stored posting (document, weight) differs from the rebuilt index: the file was not written from single Med-weight fields");
+        nterms++; npost += (int64_t)t.docs.size();
+    }
+    std::vector<int64_t> gone; for (auto& d : F.docs) if (d.deleted) gone.push_back(d.key);
+    if (!gone.empty()) { rc = infx_engine_delete_documents(e, gone.data(), (int64_t)gone.size(), nullptr); if (rc) return rc; }
+    if (checked3) { checked3[0] = n; checked3[1] = nterms; checked3[2] = npost; }
+    return INFX_OK;
+}
 
 // ---- Document.Deleted -----------------------------------------------------------------------------------------------------------------
 // DocumentCollection.DeleteDocumentsByKey (Core/DocumentCollection.cs:200-212): every document (alias / segment) with one of the keys is marked

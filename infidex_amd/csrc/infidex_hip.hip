@@ -277,8 +277,18 @@ struct infx_stream {
     size_t capNext = 0, capPrior = 0, capShBlob = 0, capAllBlobs = 0, capAllNext = 0, capChainState = 0, capChainNeed = 0;
     uint32_t shHead[4] = {0, 0, 0, 0}; uint32_t shNd = 0; int shDepth = 0; bool shSelected = false;
     void* scratch[16] = {}; size_t capScratch[16] = {};      // infx_stream_scratch
+    void *dHugeWs = nullptr, *dHugeCnt = nullptr; size_t capHugeWs = 0, capHugeCnt = 0;      // k_stage2's global-workspace pass
+    ncclComm_t comm = nullptr;                                 // infx_stream_comm: this stream's own communicator (several batches in flight per rank)
 };
 
+#define S2_HUGE_POOL_U16 (32u << 20)      // token-table pool of k_stage2's over-long-document pass: 64 MB per stream (a 700-word row takes 5.7 KB, a 32 768-token one 265 KB)
+static int32_t grow(void** p, size_t* cap, size_t need);
+static int32_t s2_huge_ready(infx_stream* s) {      // pool + bump counter of the over-long-document pass (allocated at the stream's first Stage-2 launch)
+    int32_t rc = grow(&s->dHugeWs, &s->capHugeWs, (size_t)S2_HUGE_POOL_U16 * 2); if (rc) return rc;
+    rc = grow(&s->dHugeCnt, &s->capHugeCnt, 16); if (rc) return rc;
+    if (hipMemsetAsync(s->dHugeCnt, 0, 4, s->st) != hipSuccess) return fail(INFX_EHIP, "hipMemsetAsync failed%s");
+    return INFX_OK;
+}
 static int32_t grow(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return INFX_OK;
     if (*p) hipFree(*p);
@@ -296,6 +306,8 @@ static int s2_pool() { static const int w = [] { const char* e = getenv("INFX_S2
 #define S2_LAUNCH_FAST(...) do { const int pool_ = s2_pool(); switch (s2_waves()) { case 2: k_stage2<S2_FASTD, 2><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; case 6: k_stage2<S2_FASTD, 6><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; \
                                                      case 8: k_stage2<S2_FASTD, 8><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; default: k_stage2<S2_FASTD, 4><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; } } while (0)
 #define S2_LAUNCH_SLOW(...) k_stage2<S2_MAXD, 4><<<S2_GRID(0)>>>(__VA_ARGS__, 0)
+#define S2_LAUNCH_HUGE(...) k_stage2<S2_HUGE_TOKENS, 1, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16)
+static int32_t s2_huge_ready(infx_stream* s);
 
 // ---- host <-> device transfers through pinned staging -------------------------------------------------------------------
 // The C ABI takes plain (pageable) host pointers.  Handing those to hipMemcpyAsync makes the runtime pin/unpin the caller's pages
@@ -722,18 +734,29 @@ int32_t infx_set_shard_comm(infx_index* ix, const void* id128) {
     NCCLCHK(rccl_api().init(&ix->comm, ix->nranks, id, ix->rank));
     return INFX_OK;
 }
+int32_t infx_stream_comm(infx_stream* s, const void* id128) {
+    if (!s || !id128) return fail(INFX_EINVAL, "null argument%s");
+    if (!rccl_api().ok) return fail(INFX_ENCCL, "RCCL unavailable: %s", rccl_api().why);
+    if (s->comm) return fail(INFX_EINVAL, "this stream already joined a communicator%s");
+    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    ncclUniqueId id; std::memcpy(&id, id128, sizeof id);
+    NCCLCHK(rccl_api().init(&s->comm, s->ix->nranks, id, s->ix->rank));
+    return INFX_OK;
+}
 int32_t infx_comm_allreduce_sum_u32(infx_stream* s, void* buf, uint64_t count) {
     if (!s || (count && !buf)) return fail(INFX_EINVAL, "null argument%s");
-    if (!s->ix->comm) return fail(INFX_EINVAL, "infx_set_shard_comm has not been called%s");
+    ncclComm_t c = s->comm ? s->comm : s->ix->comm;
+    if (!c) return fail(INFX_EINVAL, "infx_set_shard_comm / infx_stream_comm has not been called%s");
     if (!count) return INFX_OK;
-    NCCLCHK(rccl_api().allreduce(buf, buf, (size_t)count, ncclUint32, ncclSum, s->ix->comm, s->st)); s->unsynced = true;
+    NCCLCHK(rccl_api().allreduce(buf, buf, (size_t)count, ncclUint32, ncclSum, c, s->st)); s->unsynced = true;
     return INFX_OK;
 }
 int32_t infx_comm_allgather(infx_stream* s, const void* send, void* recv, uint64_t bytes) {
     if (!s || (bytes && (!send || !recv))) return fail(INFX_EINVAL, "null argument%s");
-    if (!s->ix->comm) return fail(INFX_EINVAL, "infx_set_shard_comm has not been called%s");
+    ncclComm_t c = s->comm ? s->comm : s->ix->comm;
+    if (!c) return fail(INFX_EINVAL, "infx_set_shard_comm / infx_stream_comm has not been called%s");
     if (!bytes) return INFX_OK;
-    NCCLCHK(rccl_api().allgather(send, recv, (size_t)bytes, ncclUint8, s->ix->comm, s->st)); s->unsynced = true;
+    NCCLCHK(rccl_api().allgather(send, recv, (size_t)bytes, ncclUint8, c, s->st)); s->unsynced = true;
     return INFX_OK;
 }
 int32_t infx_stream_scratch(infx_stream* s, int32_t slot, uint64_t bytes, void** out) {
@@ -787,9 +810,10 @@ void infx_stream_destroy(infx_stream* s) {
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
                   s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters,
-                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed};
+                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
+    if (s->comm && rccl_api().ok) rccl_api().destroy(s->comm);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
     hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1, s->evP0, s->evP1, s->evF0, s->evF1, s->evX0, s->evX1};
@@ -1014,6 +1038,9 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
                                                                                  (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 0, nullptr);
     S2_LAUNCH_SLOW(ix->d, (const infx_cov_query*)s->dCovQ, nq,
                                                                                  (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 1, nullptr);
+    { int32_t rc_ = s2_huge_ready(s); if (rc_) return rc_; }
+    S2_LAUNCH_HUGE(ix->d, (const infx_cov_query*)s->dCovQ, nq,
+                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 1, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
     s->timedCov = true;
@@ -1124,6 +1151,9 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
     S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
                                                                                  (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 0, (const int32_t*)s->dFPairs);
     S2_LAUNCH_SLOW(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
+                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 1, (const int32_t*)s->dFPairs);
+    { int32_t rc_ = s2_huge_ready(s); if (rc_) return rc_; }
+    S2_LAUNCH_HUGE(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
                                                                                  (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 1, (const int32_t*)s->dFPairs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));

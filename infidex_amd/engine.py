@@ -173,6 +173,13 @@ class SearchEngine:
                                                        _p(offs, C.c_uint64), len(fw), _p(fw, C.c_int32)))
         self._keep = None
 
+    def load_index(self, path: str):
+        """SearchEngine.Load (SearchEngine.cs:399-441) of an INFDX2 file: indexes the stored documents and verifies every stored term / posting against
+        the index just built (infx_engine_load_index).  Returns (documents, stored terms compared, stored postings compared)."""
+        c = np.zeros(3, np.int64)
+        self._check(self.L.infx_engine_load_index(self.h, str(path).encode(), _p(c, C.c_int64)))
+        return int(c[0]), int(c[1]), int(c[2])
+
     # ---- Document.Deleted (DocumentCollection.DeleteDocumentsByKey, Core/DocumentCollection.cs:200-212) ----
     def delete_documents(self, keys) -> int:
         """Marks every document with one of these DocumentKeys as deleted (index statistics are not rebuilt, as in the reference until the next

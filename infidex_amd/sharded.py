@@ -335,74 +335,157 @@ def _run_batch(sessions: Sequence[ShardSession], X, ucs, max_results, depth, ena
     return [s.phase4(m) for s, m in zip(sessions, merged)]
 
 
-class ShardedSearcher:
-    """One rank of a document-sharded deployment. All ranks must call search_packed / search_stream with the same batches."""
+_ALLREDUCE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+_ALLGATHER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
-    def __init__(self, engine: SearchEngine, comm: TorchComm, partition_planning: bool = True):
-        self.partition_planning = partition_planning and comm.world > 1
-        self.plan_group = comm.planning_group() if self.partition_planning else None      # collective: same call on every rank
-        self.sessions = [ShardSession(engine), ShardSession(engine)]
-        self.sess = self.sessions[0]
+
+class _CComm(C.Structure):      # infx_comm (include/infidex_engine.h)
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32), ("device_buffers", C.c_int32), ("reserved", C.c_int32),
+                ("allreduce_sum_u32", _ALLREDUCE), ("allgather", _ALLGATHER)]
+
+
+def native_comm(engine, comm: TorchComm, session=None, group=None):
+    """The infx_comm the C++ driver of the sharded phases (infx_session_sharded_finish) talks through.
+    nccl backend: RCCL INSIDE the library — rank 0 creates a ncclUniqueId, torch.distributed only ships its 128 bytes, and `session` (a ShardSession) joins
+    a communicator of its own; every collective of a batch is then issued by the library on the session's HIP stream over HBM buffers.
+    Other backends (gloo in the tests): host buffers + callbacks into torch.distributed on `group`.  Collective: same call order on every rank."""
+    cc = _CComm()
+    if comm.dist.get_backend() == "nccl":
+        L = engine.L; torch = comm.torch
+        idb = np.zeros(128, np.uint8)
+        if comm.rank == 0:
+            engine._check(L.infx_engine_rccl_unique_id(_p(idb, C.c_uint8)))
+        t = torch.from_numpy(idb).to(comm.device)
+        comm.dist.broadcast(t, src=0)
+        idb = np.ascontiguousarray(t.cpu().numpy())
+        if session is not None:
+            engine._check(L.infx_session_comm_rccl(session.s.h, _p(idb, C.c_uint8), C.byref(cc)))
+        else:
+            engine._check(L.infx_engine_comm_rccl(engine.h, _p(idb, C.c_uint8), C.byref(cc)))
+        return cc, ()
+    torch = comm.torch; dist = comm.dist; world = comm.world
+
+    def _ar(ctx, buf, count, stream):
+        try:
+            if count:
+                dist.all_reduce(torch.from_numpy(np.ctypeslib.as_array((C.c_int32 * count).from_address(buf))), op=dist.ReduceOp.SUM, group=group)      # in place; uint32 sums wrap like int32
+            return 0
+        except Exception:      # never let an exception cross the C frames
+            return 3
+
+    def _ag(ctx, send, recv, nbytes, stream):
+        try:
+            if nbytes:
+                s_ = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(send)))
+                r_ = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * (nbytes * world)).from_address(recv)))
+                dist.all_gather_into_tensor(r_, s_, group=group)
+            return 0
+        except Exception:
+            return 3
+    far, fag = _ALLREDUCE(_ar), _ALLGATHER(_ag)
+    cc.ctx = C.c_void_p(1); cc.rank = comm.rank; cc.nranks = world; cc.device_buffers = 0
+    cc.allreduce_sum_u32 = far; cc.allgather = fag
+    return cc, (far, fag)          # keep the callback objects alive as long as the struct is used
+
+
+class ShardedSearcher:
+    """One rank of a document-sharded deployment. All ranks must call search_packed / search_stream with the same batches.
+    native=True (default): planning, the phases and every collective between them run inside library calls (infx_session_phase0 +
+    infx_session_sharded_finish), `sessions` batches in flight per rank — each pipeline session has its own HIP stream and its own communicator
+    (RCCL inside the library; a torch.distributed group per session with other backends), batch i runs on session i mod `sessions` on every rank, so
+    the order of the collectives on each communicator is the same everywhere.
+    native=False: the same phases driven from Python one batch at a time (_run_batch — also what the in-process shard simulation of the tests uses)."""
+
+    def __init__(self, engine: SearchEngine, comm: TorchComm, partition_planning: bool = True, native=None, sessions: int = 3):
+        import os
+        self.native = (os.environ.get("INFX_SHARD_NATIVE", "1") != "0") if native is None else bool(native)
         self.comm = comm
+        self.partition_planning = partition_planning and comm.world > 1
+        K = max(1, int(sessions)) if self.native else 1
+        self.sessions = [ShardSession(engine) for _ in range(K)]
+        self.sess = self.sessions[0]
         self.last = self.sess
+        # per session: the batch communicator and (sharded planning) a gloo group for the planner's byte exchange — collective set-up, same order everywhere
+        self.ccomms, self._keep, self.plan_groups = [], [], []
+        gloo = comm.dist.get_backend() != "nccl"
+        for s in self.sessions:
+            if self.native:
+                cc, keep = native_comm(engine, comm, session=s, group=(comm.dist.new_group(backend="gloo") if gloo and K > 1 else None))
+                self.ccomms.append(cc); self._keep.append(keep)
+            self.plan_groups.append(comm.dist.new_group(backend="gloo") if self.partition_planning else None)
+        self.plan_group = self.plan_groups[0]
         on_dev = comm.device.type == "cuda" and comm.dist.get_backend() == "nccl"
         self.X = _DistX(comm, _DevBufs(comm.device) if on_dev else _HostBufs())
+        self.in_filter = 0
 
-    def _prefetch(self, s, arena, offs, depth):
+    def _prefetch(self, k, arena, offs, depth):
         """Sharded planning: this rank runs the expensive index-wide host lookups (LD1 expansion of unknown words, WordMatcher descriptors —
         ~85 % of the host time per query at 10 M documents) for its 1/W slice of the batch only; the ranks all-gather the results and import
         each other's before phase 0.  Results are unchanged: every rank holds the whole host index, the lookups are pure functions of the text."""
-        c = self.comm
+        c = self.comm; s = self.sessions[k]
         if c.world <= 1 or not self.partition_planning:
             return
         nq = len(offs) - 1
         begin, end = nq * c.rank // c.world, nq * (c.rank + 1) // c.world
         mine = s.prefetch_collect(arena, offs, begin, end, depth)
-        for r, b in enumerate(c.allgather_bytes(mine, group=self.plan_group)):
+        for r, b in enumerate(c.allgather_bytes(mine, group=self.plan_groups[k])):
             if r != c.rank and b.size:
                 s.prefetch_import(b)
 
-    def search_packed(self, arena, offs, max_results=10, depth=500, enable_coverage=True):
-        s = self.sessions[0]
-        self._prefetch(s, arena, offs, depth)
+    def _one(self, k, arena, offs, max_results, depth, enable_coverage):
+        s = self.sessions[k]
+        self._prefetch(k, arena, offs, depth)
         uc = s.phase0(arena, offs, depth)
-        return self._finish(s, uc, max_results, depth, enable_coverage)
+        self.last = s
+        if not self.native:
+            return _run_batch([s], self.X, [uc], max_results, depth, enable_coverage)[0]
+        nq, mr = s.nq, max_results
+        s.max_results = mr
+        keys = np.full((nq, mr), -1, np.int64); scores = np.zeros((nq, mr), np.float32)
+        ties = np.zeros((nq, mr), np.uint8); counts = np.zeros(nq, np.uint32); flags = np.zeros(nq, np.uint32)
+        s.e._check(s.L.infx_session_sharded_finish(s.s.h, C.byref(self.ccomms[k]), mr, int(enable_coverage), _p(keys, C.c_int64), _p(scores, C.c_float),
+                                                   _p(ties, C.c_uint8), _p(counts, C.c_uint32), _p(flags, C.c_uint32)))
+        return keys, scores, ties, counts, flags
 
-    def search_stream(self, batches, max_results=10, depth=500, enable_coverage=True, stamps=None):
-        """Pipelined stream of batches [(arena, offs), ...]: a planner thread runs phase 0 of batch i+1 (text preparation, LD1
-        expansion, k_union — host work and kernels on the OTHER session's stream, no collective) while this thread drives the
-        collective phases of batch i.  Collectives are issued by this thread only, in batch order, so their order is identical on
-        every rank.  Yields the results in order; stamps (optional list) receives (t_plan_start, t_done) per batch."""
-        import queue
+    def search_packed(self, arena, offs, max_results=10, depth=500, enable_coverage=True):
+        return self._one(0, arena, offs, max_results, depth, enable_coverage)
+
+    def search_stream(self, batches, max_results=10, depth=500, enable_coverage=True, stamps=None, timings=None):
+        """Stream of batches [(arena, offs), ...] with len(self.sessions) batches in flight: worker thread k takes batches k, k + K, ... through
+        session k (planning, kernels and collectives of one batch overlap the others'; the library calls release the GIL).  Yields the results in
+        batch order; stamps (optional list) receives (t_start, t_done) per batch, timings the session's last_timings() per batch."""
         import threading
         import time
-        free = [threading.Semaphore(1), threading.Semaphore(1)]
-        q = queue.Queue(maxsize=2)
+        K = len(self.sessions); n = len(batches)
+        done = [threading.Event() for _ in range(n)]; out = [None] * n; err = []
+        st = [None] * n; tm = [None] * n
 
-        def planner():
-            for i, (a, o) in enumerate(batches):
-                j = i % 2
-                free[j].acquire()
-                t0 = time.time()
-                try:
-                    self._prefetch(self.sessions[j], a, o, depth)
-                    q.put((j, self.sessions[j].phase0(a, o, depth), t0, None))
-                except Exception as ex:      # surfaced by the consumer
-                    q.put((j, None, t0, ex))
-                    return
+        def worker(k):
+            try:
+                for i in range(k, n, K):
+                    t0 = time.time()
+                    out[i] = self._one(k, batches[i][0], batches[i][1], max_results, depth, enable_coverage)
+                    st[i] = (t0, time.time()); tm[i] = self.sessions[k].s.last_timings()
+                    done[i].set()
+            except Exception as ex:      # surfaced by the consumer
+                err.append(ex)
+                for e_ in done:
+                    e_.set()
 
-        th = threading.Thread(target=planner, daemon=True)
-        th.start()
-        for _ in range(len(batches)):
-            j, uc, t0, ex = q.get()
-            if ex is not None:
-                raise ex
-            res = self._finish(self.sessions[j], uc, max_results, depth, enable_coverage)
+        ths = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(K)]
+        for t in ths:
+            t.start()
+        for i in range(n):
+            done[i].wait()
+            if err:
+                raise err[0]
             if stamps is not None:
-                stamps.append((t0, time.time()))
-            free[j].release()
-            yield res
-        th.join()
+                stamps.append(st[i])
+            if timings is not None:
+                timings.append(tm[i])
+            yield out[i]
+        for t in ths:
+            t.join()
 
     def set_filter(self, expr=None, enable_facets=False) -> int:
         """Query.Filter (Infiscript text, None = no filter) and Query.EnableFacets for the following searches (ResultProcessor.ApplyFilter on the merged
@@ -414,10 +497,6 @@ class ShardedSearcher:
 
     def last_facets(self, i):
         return self.last.facets(i)
-
-    def _finish(self, s, uc, max_results, depth, enable_coverage):
-        self.last = s
-        return _run_batch([s], self.X, [uc], max_results, depth, enable_coverage)[0]
 
     def last_timings(self):
         return self.last.s.last_timings()

@@ -27,15 +27,15 @@ texts = Synth.texts(qa, qo) + ["qu", "", "zzzzqq"]
 searcher = ShardedSearcher(eng, TorchComm(dist))
 a, o = pack_texts(texts)
 batches = [(a, o), pack_texts(texts[:100]), pack_texts(texts[100:])]
-res = list(searcher.search_stream(batches, 20, 500))             # pipelined stream: planner thread + collectives in batch order
+res = list(searcher.search_stream(batches, 20, 500))             # three batches in flight: a session, a stream and a communicator each
 single = searcher.search_packed(a, o, 20, 500)
 # sharded planning on (default: each rank runs the LD1 / WordMatcher host lookups for its half of the batch, blobs exchanged on the planning group)
 # and off (every rank plans the whole batch) must agree
-assert searcher.partition_planning and searcher.plan_group is not None
-off = ShardedSearcher(eng, TorchComm(dist), partition_planning=False)
+assert searcher.partition_planning and searcher.plan_group is not None and searcher.native and len(searcher.sessions) == 3
+off = ShardedSearcher(eng, TorchComm(dist), partition_planning=False, native=False)      # Python-driven phases, every rank plans the whole batch
 r_off = off.search_packed(a, o, 20, 500)
 for x, y in zip(single, r_off):
-    assert np.array_equal(x, y)
+    assert np.array_equal(x, y)      # the C++ driver (callbacks into gloo here, RCCL in production) and the Python driver agree bit for bit
 if rank == 0:
     k, sc, t, c, f = res[0]
     np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f, k1=res[1][0], c1=res[1][3], k2=res[2][0], c2=res[2][3], ks=single[0], cs=single[3])

@@ -158,7 +158,15 @@ def _distx_worker(rank, world, port, q):
     guc = X.allreduce_sum([uc])[0]
     # the sequential chain: rank 0's step, then rank 1's, on the queries that need it; every rank ends with the last shard's state
     state = X.chain([_FakeSession(rank)], np.asarray([1, 0, 1], np.uint32), np.zeros((3, 6), np.uint32))
-    q.put((rank, g, gn, m, gb, gc, guc, state))
+    # the infx_comm the C++ driver calls back into (host buffers, raw pointers): in-place sum, rank-ordered gather
+    import ctypes as C
+    import types
+    from infidex_amd.sharded import native_comm
+    cc, keep = native_comm(types.SimpleNamespace(L=None), TorchComm(dist))
+    a = np.asarray([1 + rank, 0xFFFFFFF0, 7], np.uint32); send = np.full(5, 10 + rank, np.uint8); recv = np.zeros(5 * world, np.uint8)
+    rc1 = cc.allreduce_sum_u32(cc.ctx, a.ctypes.data_as(C.c_void_p), 3, None)
+    rc2 = cc.allgather(cc.ctx, send.ctypes.data_as(C.c_void_p), recv.ctypes.data_as(C.c_void_p), 5, None)
+    q.put((rank, g, gn, m, gb, gc, guc, state, (rc1, rc2, a, recv, cc.rank, cc.nranks, cc.device_buffers)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -176,7 +184,11 @@ def test_exchange_object_of_the_sharded_driver_world2():
     got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
     for p in ps:
         p.join(60)
-    for rank, g, gn, m, gb, gc, guc, state in got:
+    for rank, g, gn, m, gb, gc, guc, state, nat in got:
+        rc1, rc2, a, recv, crank, cworld, cdev = nat
+        assert rc1 == 0 and rc2 == 0 and crank == rank and cworld == 2 and cdev == 0
+        assert a.tolist() == [3, 0xFFFFFFE0, 14]                 # uint32 sums wrap like the int32 sums the transport computes
+        assert recv.tolist() == [10] * 5 + [11] * 5
         assert g.shape == (2, 3, 4, 2) and (g[0] == 1).all() and (g[1] == 2).all()
         assert gn.dtype == np.float32 and gn[:, 0].tolist() == [0.5, 1.5]
         assert m == 137
