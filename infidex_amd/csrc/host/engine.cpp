@@ -10,6 +10,7 @@
 #include "filter.h"
 #include "infdx2.h"
 #include <mutex>
+#include <condition_variable>
 #include "../../../include/infidex_engine.h"
 #include <chrono>
 #include <map>
@@ -73,6 +74,15 @@ struct infx_session {
 };
 
 struct CompiledFilter { infx_filter* dev = nullptr; uint32_t inFilter = 0; bool counted = false; };
+// Host planning of concurrent sessions goes through a FIFO gate of `limit` planners at a time.  Each planner fans out over the whole worker pool; with
+// six sessions planning at once (the start of a stream, or any moment their phases line up) every one of them takes six times as long and the GPU
+// waits for all of them — gated, the first batches reach the device after one planning time and the pipeline fills in order.
+struct PlanGate {
+    std::mutex m; std::condition_variable cv; int inUse = 0, limit = 0; uint64_t next = 0, serving = 0;
+    void enter() { if (limit <= 0) return; std::unique_lock<std::mutex> lk(m); const uint64_t t = next++; cv.wait(lk, [&] { return t == serving && inUse < limit; }); serving++; inUse++; cv.notify_all(); }
+    void leave() { if (limit <= 0) return; { std::lock_guard<std::mutex> lk(m); inUse--; } cv.notify_all(); }
+};
+struct PlanGateHold { PlanGate& g; explicit PlanGateHold(PlanGate& x) : g(x) { g.enter(); } ~PlanGateHold() { g.leave(); } };
 struct infx_engine {
     // non-indexed document fields (DocumentFields) as dictionary-encoded columns + compiled Infiscript filters (config 5)
     std::vector<filt::Column> columns; std::mutex filterMu; std::unordered_map<std::string, CompiledFilter> filters;
@@ -81,6 +91,7 @@ struct infx_engine {
     void invalidate_filter_counts() { std::lock_guard<std::mutex> lk(filterMu); for (auto& kv : filters) kv.second.counted = false; }
     void retire_filters() { std::lock_guard<std::mutex> lk(filterMu); for (auto& kv : filters) if (kv.second.dev) retiredFilters.push_back(kv.second.dev); filters.clear(); }
     HostIndex ix;
+    PlanGate gate;
     infx_engine_config cfg{};
     infx_index* dev = nullptr;
     bool indexed = false;
@@ -126,6 +137,7 @@ int32_t infx_engine_create(const infx_engine_config* cfg, infx_engine** out) {
     h.maxDepth = cfg->max_depth > 0 ? cfg->max_depth : 500;
     h.threads = cfg->threads;
     e->threads = cfg->threads > 0 ? cfg->threads : effective_cpus();
+    { const char* g = getenv("INFX_PLAN_GATE"); e->gate.limit = g ? atoi(g) : std::max(1, e->threads / 8); }      // 0 = no gate
     if (cfg->device >= 0) {
         infx_config dc{}; dc.device = cfg->device; dc.range_docs = cfg->range_docs; dc.max_depth = h.maxDepth; dc.flags = cfg->no_exact_replay ? INFX_CFG_NO_EXACT_REPLAY : 0;
         int32_t rc = infx_create(&dc, &e->dev);
@@ -658,10 +670,13 @@ static int32_t fused_inputs_for_phase3(infx_engine* e, infx_session* S, int32_t 
 static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
                                   int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                   uint32_t* out_counts, uint32_t* out_flags) {
-    int32_t rc = ph_plan(e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
-    rc = ph_plan_finish(e, S, S->batch->pendingCounts.data()); if (rc) return rc;
+    int32_t rc; FusedIn FI;
+    {   PlanGateHold hold(e->gate);
+        rc = ph_plan(e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
+        rc = ph_plan_finish(e, S, S->batch->pendingCounts.data()); if (rc) return rc;
+        rc = build_fused_inputs(e, S, max_results, enable_coverage, FI); if (rc) return rc;
+    }
     Batch& B = *S->batch; const HostIndex& ix = e->ix;
-    FusedIn FI; rc = build_fused_inputs(e, S, max_results, enable_coverage, FI); if (rc) return rc;
     auto& fq = FI.fq; auto& cq = FI.cq; auto& lists = FI.lists; auto& owned = FI.owned;
     B.t2 = now_ms();
     const bool dbg = e->cfg.want_features != 0;
@@ -761,6 +776,7 @@ int32_t infx_engine_set_shard(infx_engine* e, int32_t rank, int32_t nranks) {
 int32_t infx_engine_shard_info(infx_engine* e, int32_t* base, int32_t* n) { if (!e) return INFX_EINVAL; if (base) *base = e->shardBase; if (n) *n = e->shardN; return INFX_OK; }
 int32_t infx_session_phase0(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, uint32_t* nunions) {
     if (!S) return efail(INFX_EINVAL, "null session");
+    PlanGateHold hold(S->e->gate);
     int32_t rc = ph_plan(S->e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
     if (nunions) *nunions = (uint32_t)S->batch->pending.size();
     static const bool hostPhases = getenv("INFX_PHASED") != nullptr;
