@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
+    # stdout carries ONE line, the result: everything else a library prints there (RCCL's start-up banner, C stdio) goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -356,10 +360,11 @@ def main():
     if rank == 0:
         try:
             import ctypes
-            ctypes.CDLL(None).fflush(None)        # RCCL's start-up banner sits in the C stdio buffer: flush it BEFORE the result line
+            ctypes.CDLL(None).fflush(None)        # RCCL's start-up banner sits in the C stdio buffer: out it goes (to stderr) before the result line
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <string>
 #include <vector>
+#include <unordered_map>
 #include <algorithm>
 #include <mutex>
 #include <dlfcn.h>
@@ -163,6 +164,8 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 
 #include "stage1.hip.inc"
 #include "stage1b.hip.inc"
+#define ACC_V3_DEFAULT 0
+#include "stage1c.hip.inc"
 #include "exact1.hip.inc"
 #include "exact3.hip.inc"
 #include "exactsh.hip.inc"
@@ -428,8 +431,25 @@ template <int R, int MW, int CAP> static bool acc2_launch(infx_stream* s, uint32
 // k_accumulate2 (stage1b.hip.inc, the "mask scatter" design) is a measured alternative, bit-identical to k_accumulate but slower on the 10 M-doc batch
 // (10.7 vs 7.5 ms, profiles/r03_accumulate2.md): it runs only with INFX_ACC_V2=1 (A/B parity test, profiling) and for batches of <= 64-term queries
 static bool acc_v1_forced() { static const bool v = [] { const char* e = getenv("INFX_ACC_V2"); return !(e && e[0] == '1'); }(); return v; }
+// k_accumulate3 (stage1c.hip.inc, "probe, pool, score"): same LDS layout as k_accumulate.  INFX_ACC_V3=0 falls back to k_accumulate (A/B test, profiling).
+static bool acc_v3_enabled() { static const bool v = [] { const char* e = getenv("INFX_ACC_V3"); return ACC_V3_DEFAULT ? !(e && e[0] == '0') : (e && e[0] == '1'); }(); return v; }
+template <int R, int MW> static bool acc3_launch(infx_stream* s, uint32_t nq, Arena ar, int useGrp) {
+    static const bool ok = [] { hipFuncAttributes a{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate3<R, MW>) == hipSuccess && a.sharedSizeBytes == 0; }();
+    if (!ok) return false;                                   // LDS8 addresses the dynamic block from LDS address 0: no static __shared__ allowed
+    const int stripe = acc_stripe();
+    static const int dbg = [] { const char* e = getenv("INFX_ACC_DBG"); return e ? atoi(e) : 0; }();      // kernel ablation for profiling only (results are then meaningless)
+    const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
+    const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
+    k_accumulate3<R, MW><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
+                                                                            (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, dbg);
+    return true;
+}
 static int acc2_cap() { static const int v = [] { const char* e = getenv("INFX_ACC2_CAP"); const int x = e ? atoi(e) : 0; return x == 64 ? 64 : 128; }(); return v; }
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp, int maxRef) {
+    if (maxRef <= 64 && acc_v3_enabled() && acc_v1_forced()) {
+        if (!(maxRef <= 32 ? acc3_launch<R, 1>(s, nq, ar, useGrp) : acc3_launch<R, 2>(s, nq, ar, useGrp))) s->accLayoutBad = true;
+        return;
+    }
     if (maxRef <= 64 && !acc_v1_forced()) {
         bool ok;
         if (acc2_cap() == 64) ok = maxRef <= 32 ? acc2_launch<R, 1, 64>(s, nq, ar, useGrp) : acc2_launch<R, 2, 64>(s, nq, ar, useGrp);
@@ -441,7 +461,7 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
     const int stripe = acc_stripe();
     const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
-    const uint64_t blocks = (uint64_t)nq * ((s->ix->d.nRanges + stripe - 1) / stripe);
+    const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
     if (ar.maskWords == 2)
         k_accumulate<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
                                                                            (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats);
@@ -828,7 +848,7 @@ void infx_stream_destroy(infx_stream* s) {
 static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uint32_t nterms, const infx_term* terms,
                            uint32_t extra_n, const int32_t* extra_docs) {
     infx_index* ix = s->ix;
-    if ((uint64_t)nq * ix->d.nRanges > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nq * nRanges exceeds the grid limit; split the batch%s");
+    if ((uint64_t)nq * ((uint64_t)ix->d.nRanges + 8) > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nq * nRanges exceeds the grid limit; split the batch%s");
     // translate + capacity bound.  A virtual term given as a MEMBER LIST (infx_term.reserved == 1: extra_docs[extra_off..+len) are index
     // term ids) is expanded into one device entry per member, all sharing the term's idf / role / rank and a dedupe group.
     std::vector<DevQuery> dq(nq); std::vector<DevTerm> dt; dt.reserve(nterms + 64);
@@ -888,6 +908,33 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
         bound += std::min<unsigned long long>(qb, (unsigned long long)ix->d.N);
     }
     qbase[nq] = bound;
+    {   // INFX_ACC_SHARE_STATS=1 (profiling): how many posting bytes do the queries of the batch share?  total = sum over (query, list) of the list length;
+        // distinct = every list once; by XCD = every list once per XCD under the current block -> XCD assignment (q % 8) and under a chunked assignment of
+        // the queries sorted by their longest list
+        static const bool want = [] { const char* e = getenv("INFX_ACC_SHARE_STATS"); return e && e[0] == '1'; }();
+        if (want) {
+            unsigned long long total = 0, distinct = 0, byMod = 0, byChunk = 0;
+            std::vector<std::pair<unsigned long long, uint32_t>> order(nq);       // (begin of the longest list, query)
+            for (uint32_t i = 0; i < nq; i++) {
+                unsigned long long bestLen = 0, bestBeg = 0;
+                for (uint32_t k = 0; k < dq[i].numTerms; k++) { const DevTerm& D = dt[dq[i].termOff + k]; const unsigned long long L = D.end - D.begin; total += L; if (!D.isVirtual && L > bestLen) { bestLen = L; bestBeg = D.begin; } }
+                order[i] = {bestBeg, i};
+            }
+            std::sort(order.begin(), order.end());
+            std::vector<uint32_t> chunkOf(nq); for (uint32_t j = 0; j < nq; j++) chunkOf[order[j].second] = (uint32_t)((uint64_t)j * 8 / nq);
+            std::unordered_map<unsigned long long, uint32_t> seenAll, seenMod, seenChunk;      // begin -> bitmask of XCDs that already fetch it
+            for (uint32_t i = 0; i < nq; i++)
+                for (uint32_t k = 0; k < dq[i].numTerms; k++) {
+                    const DevTerm& D = dt[dq[i].termOff + k]; const unsigned long long L = D.end - D.begin;
+                    if (D.isVirtual & 5) { distinct += L; byMod += L; byChunk += L; continue; }
+                    if (!seenAll[D.begin]++) distinct += L;
+                    uint32_t& m = seenMod[D.begin]; if (!(m & (1u << (i & 7)))) { m |= 1u << (i & 7); byMod += L; }
+                    uint32_t& c = seenChunk[D.begin]; if (!(c & (1u << chunkOf[i]))) { c |= 1u << chunkOf[i]; byChunk += L; }
+                }
+            fprintf(stderr, "[infx] posting sharing of the batch (%u queries): total %.2f G postings, distinct %.2f G (x%.2f), once per XCD with q %% 8: %.2f G (x%.2f), with sorted chunks: %.2f G (x%.2f)\n",
+                    nq, total * 1e-9, distinct * 1e-9, (double)total / std::max(1ull, distinct), byMod * 1e-9, (double)total / std::max(1ull, byMod), byChunk * 1e-9, (double)total / std::max(1ull, byChunk));
+        }
+    }
     // arena
     size_t need = (size_t)bound + 64;
     if (need > s->arCap) {

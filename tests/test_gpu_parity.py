@@ -409,7 +409,7 @@ def test_high_term_frequencies():
 
 
 def test_accumulate_designs_agree_bit_for_bit(tmp_path):
-    """k_accumulate (tf scatter + probe, the production kernel) and k_accumulate2 (mask scatter, INFX_ACC_V2=1: a measured alternative) are the same
+    """k_accumulate (tf scatter + probe), k_accumulate2 (mask scatter, INFX_ACC_V2=1: a measured alternative) and k_accumulate3 (probe, pool, score) are the same
     arithmetic in the same order: final rows, fp32 scores and the Stage-1 rows (ids and score bits) of a fuzzy batch must be identical, with deletions too."""
     import os
     import subprocess
@@ -434,13 +434,14 @@ for tag in ("plain", "deleted"):
 np.savez(sys.argv[1], **out)
 '''
     res = []
-    for v1 in ("0", "1"):
-        env = dict(os.environ); env["INFX_ACC_V2"] = v1
+    for v2, v3 in (("0", "0"), ("1", "0"), ("0", "1")):        # k_accumulate, k_accumulate2, k_accumulate3
+        env = dict(os.environ); env["INFX_ACC_V2"] = v2; env["INFX_ACC_V3"] = v3
         env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        out = str(tmp_path / f"acc{v1}.npz")
+        out = str(tmp_path / f"acc{v2}{v3}.npz")
         subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=900)
         res.append(np.load(out))
     assert len(res[0].files) == 14
-    for key in res[0].files:
-        assert np.array_equal(res[0][key], res[1][key]), key
+    for other in res[1:]:
+        for key in res[0].files:
+            assert np.array_equal(res[0][key], other[key]), key
     assert res[0]["plain_s1k"].size > 1000
