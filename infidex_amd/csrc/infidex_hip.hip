@@ -295,7 +295,9 @@ static int32_t s2_huge_ready(infx_stream* s) {      // pool + bump counter of th
 static int32_t grow(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return INFX_OK;
     if (*p) hipFree(*p);
-    size_t n = std::max(need, *cap * 2);
+    // a quarter of headroom: batches of one workload differ by a few per cent, and a reallocation (hipFree + hipMalloc synchronise the device) in a
+    // stream's second batch would stall every other stream's batch in flight
+    size_t n = std::max(need + need / 4 + 4096, *cap * 2);
     if (hipMalloc(p, n) != hipSuccess) { *p = nullptr; *cap = 0; return fail(INFX_ENOMEM, "hipMalloc workspace failed%s"); }
     *cap = n; return INFX_OK;
 }
@@ -940,7 +942,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     if (need > s->arCap) {
         if (need > ((size_t)1 << 31)) return fail(INFX_ECAPACITY, "candidate superset bound exceeds 2^31 entries; split the batch%s");
         if (s->arDoc) { hipFree(s->arDoc); hipFree(s->arScore); hipFree(s->arCls); s->arDoc = nullptr; }
-        size_t n = std::max(need, s->arCap * 2);
+        size_t n = std::max(need + need / 4, s->arCap * 2);     // headroom as in grow()
         if (hipMalloc((void**)&s->arDoc, n * 4) != hipSuccess || hipMalloc((void**)&s->arScore, n * 4) != hipSuccess || hipMalloc((void**)&s->arCls, n) != hipSuccess)
             return fail(INFX_ENOMEM, "arena allocation failed%s");
         s->arCap = n;
