@@ -166,6 +166,8 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 #include "stage1b.hip.inc"
 #define ACC_V3_DEFAULT 0
 #include "stage1c.hip.inc"
+#define ACC_V4_DEFAULT 0
+#include "stage1d.hip.inc"
 #include "exact1.hip.inc"
 #include "exact3.hip.inc"
 #include "exactsh.hip.inc"
@@ -447,7 +449,34 @@ template <int R, int MW> static bool acc3_launch(infx_stream* s, uint32_t nq, Ar
     return true;
 }
 static int acc2_cap() { static const int v = [] { const char* e = getenv("INFX_ACC2_CAP"); const int x = e ? atoi(e) : 0; return x == 64 ? 64 : 128; }(); return v; }
+// k_accumulate4 (stage1d.hip.inc): 4-bit tf cells, passes of SUP x R documents.  INFX_ACC_V4 = 1 / 0 overrides the default; INFX_ACC_SUP = 2 (default) or 4.
+static bool acc_v4_enabled() { static const bool v = [] { const char* e = getenv("INFX_ACC_V4"); return ACC_V4_DEFAULT ? !(e && e[0] == '0') : (e && e[0] == '1'); }(); return v; }
+static int acc_sup() { static const int v = [] { const char* e = getenv("INFX_ACC_SUP"); return (e && atoi(e) == 4) ? 4 : 2; }(); return v; }
+template <int R, int MW, int SUP> static bool acc4_launch(infx_stream* s, uint32_t nq, Arena ar, int useGrp) {
+    static const bool ok = [] { hipFuncAttributes a{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate4<R, MW, SUP>) == hipSuccess && a.sharedSizeBytes == 0; }();
+    if (!ok) return false;                                   // LDS32 addresses the dynamic block from LDS address 0: no static __shared__ allowed
+    static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
+    const int stripe = std::max(SUP, (acc_stripe() / SUP) * SUP);                   // whole passes per block
+    constexpr size_t SR = (size_t)R * SUP;
+    const size_t lds = SR / 2 + 272 + (SR / 32 + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
+    const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);
+    k_accumulate4<R, MW, SUP><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
+                                                                                 (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, dbgSkip);
+    return true;
+}
+// passes of SUP x R documents must divide a 65 536-id container, keep a slice within 16 bits of postings, and leave the packed sentinel id (0xFFFFFF)
+// outside the last pass
+template <int R, int SUP> static bool acc4_fits(const infx_index* ix) {
+    return (size_t)R * SUP <= 32768 && (65536 % ((size_t)R * SUP)) == 0 && (!ix->d.packed || (uint64_t)ix->d.N + (uint64_t)R * SUP + 512 < (1ull << 24));
+}
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp, int maxRef) {
+    if (acc_v4_enabled() && acc_v1_forced() && !acc_v3_enabled()) {
+        const int mw = ar.maskWords == 2 ? 2 : 1;
+        bool done = false, ok = true;
+        if (acc_sup() == 4 && acc4_fits<R, 4>(s->ix)) { ok = mw == 2 ? acc4_launch<R, 2, 4>(s, nq, ar, useGrp) : acc4_launch<R, 1, 4>(s, nq, ar, useGrp); done = true; }
+        else if (acc4_fits<R, 2>(s->ix)) { ok = mw == 2 ? acc4_launch<R, 2, 2>(s, nq, ar, useGrp) : acc4_launch<R, 1, 2>(s, nq, ar, useGrp); done = true; }
+        if (done) { if (!ok) s->accLayoutBad = true; return; }
+    }
     if (maxRef <= 64 && acc_v3_enabled() && acc_v1_forced()) {
         if (!(maxRef <= 32 ? acc3_launch<R, 1>(s, nq, ar, useGrp) : acc3_launch<R, 2>(s, nq, ar, useGrp))) s->accLayoutBad = true;
         return;

@@ -409,7 +409,7 @@ def test_high_term_frequencies():
 
 
 def test_accumulate_designs_agree_bit_for_bit(tmp_path):
-    """k_accumulate (tf scatter + probe), k_accumulate2 (mask scatter, INFX_ACC_V2=1: a measured alternative) and k_accumulate3 (probe, pool, score) are the same
+    """k_accumulate (tf scatter + probe), k_accumulate2 (mask scatter), k_accumulate3 (probe, pool, score) and k_accumulate4 (4-bit cells, wider passes) are the same
     arithmetic in the same order: final rows, fp32 scores and the Stage-1 rows (ids and score bits) of a fuzzy batch must be identical, with deletions too."""
     import os
     import subprocess
@@ -434,10 +434,15 @@ for tag in ("plain", "deleted"):
 np.savez(sys.argv[1], **out)
 '''
     res = []
-    for v2, v3 in (("0", "0"), ("1", "0"), ("0", "1")):        # k_accumulate, k_accumulate2, k_accumulate3
-        env = dict(os.environ); env["INFX_ACC_V2"] = v2; env["INFX_ACC_V3"] = v3
+    variants = [dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate
+                dict(INFX_ACC_V2="1", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate2
+                dict(INFX_ACC_V2="0", INFX_ACC_V3="1", INFX_ACC_V4="0"),                      # k_accumulate3
+                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="1", INFX_ACC_SUP="2"),    # k_accumulate4, passes of 2 ranges
+                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="1", INFX_ACC_SUP="4")]    # ... of 4 ranges
+    for vi, var in enumerate(variants):
+        env = dict(os.environ); env.update(var)
         env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        out = str(tmp_path / f"acc{v2}{v3}.npz")
+        out = str(tmp_path / f"acc{vi}.npz")
         subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=900)
         res.append(np.load(out))
     assert len(res[0].files) == 14
