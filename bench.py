@@ -284,8 +284,9 @@ def main():
         "stage_ms_per_step": stage_me,
         "roofline": {"kernel": "k_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "limiter": "instruction issue, not bandwidth: the kernel is priced against the HBM roofline (byte streaming, no MFMA work) but its time is set by "
-                                "the VALU / SALU / LDS instructions of the (posting list, doc range) visits (DESIGN.md section 4; counters in profiles/)",
+                     "limiter": "instruction issue and latency, not bandwidth: the kernel is priced against the HBM roofline (byte streaming, no MFMA work) but its "
+                                "time is set by the VALU / SALU / LDS instructions of the (posting list, doc range) visits - vector ALUs 72 % busy, 46 % of a wave's time in "
+                                "s_waitcnt (profiles/r03_final_10m.md); a kernel that only loads random 512-byte slices reaches 5.2-5.7 TB/s on this GPU (tools/bench_slices.hip)",
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": acc_ms,
                      "streamed_bytes_per_launch": streamed, "stage1_candidates_per_launch": float(np.mean([t["stage1_candidates"] for t in roof])),
                      "stage2_rows_per_launch": float(np.mean([t["stage2_candidates"] for t in roof])), "exact_replays_per_launch": float(np.mean([t["exact_replays"] for t in roof])), "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
