@@ -59,6 +59,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    node_local_rank = local_rank          # rank within the node (the device index below may wrap when ranks share a GPU in tests)
     dist = None
     force_sharded = os.environ.get("INFX_FORCE_SHARDED") == "1"      # exercise the sharded / RCCL code path with a single rank
     if world > 1 or force_sharded:
@@ -103,8 +104,14 @@ def main():
         args.docs = full
     syn = Synth(args.config, docs=(None if args.docs == full else args.docs), threads=bthreads)
     k = syn.cfg["k"]
+    # one host-index build per node (N > 1): the node's leader generates and indexes the corpus with every core and hands the host index to the other
+    # ranks through /dev/shm (infidex_amd/sharded.py: index_flat_per_node); INFX_SHARED_HOST_INDEX=0: every rank builds its own, as before
+    share_build = world > 1 and os.environ.get("INFX_SHARED_HOST_INDEX", "1") != "0"
+    leader = (not share_build) or node_local_rank == 0
     t0 = time.time()
-    arena, offs = syn.docs()
+    if share_build and leader:
+        syn = Synth(args.config, docs=(None if args.docs == full else args.docs), threads=args.build_threads or max(1, min(64, quota_cpus())))
+    arena, offs = syn.docs() if leader else (None, None)
     t_gen = time.time() - t0
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle's index is built AFTER the timed GPU region (it would compete for the CPU quota) ----
@@ -121,7 +128,11 @@ def main():
         eng = create_sharded_engine(rank, world, local_rank, threads=bthreads, range_docs=args.range_docs)
     else:
         eng = SearchEngine.create_default(device=local_rank, threads=bthreads, range_docs=args.range_docs)
-    eng.index_flat(None, arena, offs, syn.field_weights)
+    if share_build:
+        from infidex_amd.sharded import index_flat_per_node
+        index_flat_per_node(eng, dist.barrier, node_local_rank, max(1, min(64, quota_cpus())), None, arena, offs, syn.field_weights, tag=os.environ.get("MASTER_PORT", "0"))
+    else:
+        eng.index_flat(None, arena, offs, syn.field_weights)
     flt = syn.cfg.get("filter")                       # config 5: Query.Filter + Query.EnableFacets on device-resident columns
     cols5 = None
     if flt:

@@ -163,6 +163,15 @@ int32_t infx_engine_delete_documents(infx_engine* e, const int64_t* keys, int64_
  * builder produces for the stored texts (e.g. written from differently weighted fields); INFX_EINVAL for a foreign or corrupted file. */
 int32_t infx_engine_load_index(infx_engine* e, const char* path, int64_t* checked3);
 int32_t infx_engine_restore_documents(infx_engine* e);      /* clears every Deleted flag */
+/* One host-index build per node instead of one per rank (document shards: every process needs the whole host index — global df / avgdl / N, the term and
+ * word dictionaries, the WordMatcher lists).  The node's leader indexes the documents (infx_engine_set_build_threads lets that build use every
+ * core of the node while planning keeps the rank's share), saves the host index to a node-local file (e.g. under /dev/shm) and the other ranks call
+ * infx_engine_index_from_host_cache INSTEAD of infx_engine_index_documents: they read the arrays back and upload their own shard.  The file pins its
+ * layout version, the configuration (n-gram, stop-term, WordMatcher, synonym settings) and the index fingerprint; anything else is refused
+ * (INFX_EINVAL).  A transient hand-off between the processes of one build — not the reference's INFDX2 format (infx_engine_load_index). */
+int32_t infx_engine_set_build_threads(infx_engine* e, int32_t threads);     /* 0 = the engine's thread count */
+int32_t infx_engine_save_host_index(infx_engine* e, const char* path);
+int32_t infx_engine_index_from_host_cache(infx_engine* e, const char* path);
 
 /* ---- Query.Filter (Infiscript, Api/FilterParser.cs) and Query.EnableFacets (config 5) -------------------------------------------------
  * Non-indexed document fields are given as columns (one value per indexed document, in indexing order); the post-filter of the returned

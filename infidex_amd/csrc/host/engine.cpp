@@ -9,6 +9,7 @@
 #include "query.h"
 #include "filter.h"
 #include "infdx2.h"
+#include "hostcache.h"
 #include <mutex>
 #include <condition_variable>
 #include "../../../include/infidex_engine.h"
@@ -100,6 +101,7 @@ struct infx_engine {
     bool keysAreIds = false;
     std::vector<uint8_t> deleted;     // Document.Deleted per global internal id; empty = nothing deleted
     int threads = 1;
+    int buildThreads = 0;             // > 0: threads of the index build only (infx_engine_set_build_threads)
     infx_session* def = nullptr;      // default session (single-caller API)
     // document sharding: this engine's GPU holds internal ids [shardBase, shardBase + shardN) of the corpus
     int rank = 0, nranks = 1; int32_t shardBase = 0, shardN = 0;
@@ -159,6 +161,7 @@ void infx_engine_destroy(infx_engine* e) {
     delete e;
 }
 
+static int32_t finish_index(infx_engine* e);
 // SearchEngine.IndexDocuments: n documents x field_count fields (UTF-16 arena + offsets), keys may be null (key = index)
 int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* keys, const uint16_t* arena, const uint64_t* offs,
                                     int32_t field_count, const int32_t* field_weights) {
@@ -166,9 +169,19 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
     if (e->indexed) return efail(INFX_EINVAL, "this engine instance is already indexed (re-indexing: create a new engine)");
     if (n > 0x7FFFFFF0ll) return efail(INFX_EINVAL, "too many documents");
     DocSource src{n, field_count, field_weights, keys, (const u16*)arena, offs};
-    build_index(src, e->ix);
+    {
+        const int planThreads = e->ix.cfg.threads;
+        if (e->buildThreads > 0) e->ix.cfg.threads = e->buildThreads;      // a node's leader rank builds with every core while the other ranks wait for its cache
+        build_index(src, e->ix);
+        e->ix.cfg.threads = planThreads;
+    }
     e->keysAreIds = (keys == nullptr);
-    if (keys) { e->keyToFirst.reserve((size_t)n * 2); for (int64_t d = 0; d < n; d++) e->keyToFirst.emplace(keys[d], (int32_t)d); }
+    return finish_index(e);
+}
+
+// After the host index exists (built here or read from a node-local cache): key map, shard bounds, upload of this rank's slice
+static int32_t finish_index(infx_engine* e) {
+    if (!e->keysAreIds) { const int64_t n = e->ix.N; e->keyToFirst.reserve((size_t)n * 2); for (int64_t d = 0; d < n; d++) e->keyToFirst.emplace(e->ix.docKey[d], (int32_t)d); }
     {
         // contiguous doc-range shards of whole 65 536-id Roaring containers: the reference scores its candidates in chunks that never span a
         // container (Bm25Scorer.cs:195-280), so with boundaries at container multiples its sequential walk is the shards' walks one after the other and
@@ -1344,6 +1357,33 @@ int32_t infx_engine_device_handles(infx_engine* e, infx_index** idx, infx_stream
 // (which uploads the shard as infx_engine_index_documents does), Deleted flags are applied, and every stored term is compared with the index just
 // built.  *checked3 = {documents, stored terms compared, stored postings compared}.  INFX_EUNSUPPORTED: the stored postings are not what this
 // builder produces for the stored texts (multi-field weights, other tokenizer settings); INFX_EINVAL: not an INFDX2 file / corrupted.
+// ---- node-local cache of the host index (host/hostcache.h): one build per node instead of one per rank ------------------------------------
+static uint64_t syn_hash(const SynMap& m) {
+    uint64_t h = 1469598103934665603ull;
+    for (auto& pr : m.parent) for (const ustr* t : {&pr.first, &pr.second}) { for (u16 c : *t) { h ^= c; h *= 1099511628211ull; } h ^= 0xFFFFu; h *= 1099511628211ull; }
+    return h;
+}
+int32_t infx_engine_set_build_threads(infx_engine* e, int32_t threads) {
+    if (!e || threads < 0) return efail(INFX_EINVAL, "bad arguments");
+    e->buildThreads = threads; return INFX_OK;
+}
+int32_t infx_engine_save_host_index(infx_engine* e, const char* path) {
+    if (!e || !path) return efail(INFX_EINVAL, "null argument");
+    if (!e->indexed) return efail(INFX_EINVAL, "index the documents first");
+    const std::string err = hostcache::save(path, e->ix, e->keysAreIds, hostcache::config_signature(e->ix.cfg, syn_hash(e->ix.cfg.syn)), index_fingerprint(e->ix));
+    if (!err.empty()) return efail(INFX_EINVAL, err.c_str());
+    return INFX_OK;
+}
+int32_t infx_engine_index_from_host_cache(infx_engine* e, const char* path) {
+    if (!e || !path) return efail(INFX_EINVAL, "null argument");
+    if (e->indexed) return efail(INFX_EINVAL, "this engine instance is already indexed (re-indexing: create a new engine)");
+    bool keysAreIds = true;
+    const std::string err = hostcache::load(path, e->ix, keysAreIds, hostcache::config_signature(e->ix.cfg, syn_hash(e->ix.cfg.syn)), &index_fingerprint);
+    if (!err.empty()) return efail(INFX_EINVAL, err.c_str());
+    e->keysAreIds = keysAreIds;
+    return finish_index(e);
+}
+
 int32_t infx_engine_load_index(infx_engine* e, const char* path, int64_t* checked3) {
     if (!e || !path) return efail(INFX_EINVAL, "null argument");
     if (e->indexed) return efail(INFX_EINVAL, "this engine instance is already indexed");

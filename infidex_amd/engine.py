@@ -180,6 +180,19 @@ class SearchEngine:
         self._check(self.L.infx_engine_load_index(self.h, str(path).encode(), _p(c, C.c_int64)))
         return int(c[0]), int(c[1]), int(c[2])
 
+    # ---- one host-index build per node (document shards; include/infidex_engine.h) ----
+    def set_build_threads(self, threads: int):
+        """Threads of the index build only (a node's leader rank builds with every core while planning keeps the rank's share)."""
+        self._check(self.L.infx_engine_set_build_threads(self.h, int(threads)))
+
+    def save_host_index(self, path: str):
+        """Writes the host index (dictionaries, postings, WordMatcher lists, texts) to a node-local file for the node's other ranks."""
+        self._check(self.L.infx_engine_save_host_index(self.h, str(path).encode()))
+
+    def index_from_host_cache(self, path: str):
+        """Instead of index_flat / index_documents: reads the host index a leader rank saved and uploads this rank's shard."""
+        self._check(self.L.infx_engine_index_from_host_cache(self.h, str(path).encode()))
+
     # ---- Document.Deleted (DocumentCollection.DeleteDocumentsByKey, Core/DocumentCollection.cs:200-212) ----
     def delete_documents(self, keys) -> int:
         """Marks every document with one of these DocumentKeys as deleted (index statistics are not rebuilt, as in the reference until the next

@@ -23,6 +23,7 @@ simulation of W shards on one GPU (W local sessions, the "collectives" are numpy
 import ctypes as C
 from typing import List, Sequence
 
+import os
 import numpy as np
 
 from .engine import SearchEngine, Session, _p, INFX_NFEAT  # noqa: F401
@@ -100,6 +101,27 @@ def create_sharded_engine(rank: int, world: int, device: int, **kw) -> SearchEng
     eng = SearchEngine.create_default(device=device, **kw)
     eng._check(eng.L.infx_engine_set_shard(eng.h, rank, world))
     return eng
+
+
+def index_flat_per_node(eng: SearchEngine, barrier, local_rank: int, node_cpus: int, keys, arena, offs, field_weights, tag: str, cache_dir: str = "/dev/shm"):
+    """One host-index build per NODE instead of one per rank.  The node's leader (local rank 0) indexes the documents with every core of the node and
+    saves the host index under `cache_dir`; the node's other ranks wait (`barrier()`: any barrier over the ranks, e.g. torch.distributed.barrier), read
+    the arrays back and upload their own shard; the leader removes the file after a second barrier.  `tag` must be the same on the ranks of a node and
+    unique per job (e.g. MASTER_PORT).  Every rank ends up with the same host index as if it had called index_flat itself."""
+    path = os.path.join(cache_dir, f"infx_host_index_{tag}.bin")
+    if local_rank == 0:
+        eng.set_build_threads(node_cpus)
+        eng.index_flat(keys, arena, offs, field_weights)
+        eng.save_host_index(path)
+    barrier()
+    if local_rank != 0:
+        eng.index_from_host_cache(path)
+    barrier()
+    if local_rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
 
 
 class ShardSession:

@@ -17,11 +17,13 @@ import torch, torch.distributed as dist
 torch.cuda.init()
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-from infidex_amd.sharded import create_sharded_engine, ShardedSearcher, TorchComm
+from infidex_amd.sharded import create_sharded_engine, ShardedSearcher, TorchComm, index_flat_per_node
 from infidex_amd.engine import pack_texts
 from tools.synth import Synth
 s = Synth(4, docs=140000); arena, offs = s.docs()
-eng = create_sharded_engine(rank, world, 0); eng.index_flat(None, arena, offs, s.field_weights)
+# one host-index build for the node: rank 0 indexes and saves the host index, rank 1 reads it back and uploads its own shard
+eng = create_sharded_engine(rank, world, 0)
+index_flat_per_node(eng, dist.barrier, rank, 4, None, arena, offs, s.field_weights, tag=os.environ["MASTER_PORT"], cache_dir=os.path.dirname(sys.argv[1]))
 qa, qo = s.queries(300, qseed=91)
 texts = Synth.texts(qa, qo) + ["qu", "", "zzzzqq"]
 searcher = ShardedSearcher(eng, TorchComm(dist))
