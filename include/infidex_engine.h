@@ -200,6 +200,8 @@ int64_t infx_session_prefetch_pending(infx_session* s);        /* imported WordM
 /* Measurement hook (no device needed): single-threaded host planning cost of a batch by stage, microseconds per query:
  * out_us[0] plan_tokens, [1] of it LD1 walks, [2] plan_finish, [3] wm_collect, [4] prepare_cov_query. */
 int32_t infx_engine_host_plan_profile(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, double* out_us);
+/* Entries of the LD1 expansion cache (least recently used, at most 1000: VectorModel.cs:42). */
+int64_t infx_engine_fuzzy_cache_size(infx_engine* e);
 /* Switches infx_engine_config.want_features at run time (the introspection buffers behind infx_engine_last_stage1 / _last_stage2). */
 int32_t infx_engine_set_introspection(infx_engine* e, int32_t on);
 int32_t infx_engine_normalize(const uint16_t* s, int32_t len, int32_t lower, uint16_t* out, int32_t cap);

@@ -264,9 +264,16 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
     B.tTok = now_ms() - B.t0;
     {   // every fuzzy union this batch uses is materialised on the device (this shard's slice); |union| = its df (sharded:
         // summed over the shards by the caller)
+        // One union per distinct misspelt WORD of the batch, in first-occurrence order: the list must be the same on every rank (the counts are
+        // all-reduced position by position), so it may not depend on the state of the expansion cache — two queries of a batch can hold two
+        // FuzzyUnion objects for one word when the LRU cache evicted it in between (the objects have the same members: LD1 is a function of the word).
         B.pending.clear(); B.unionIdx.clear();
+        std::unordered_map<std::u16string, uint32_t> byWord;
         for (auto& P : plans) for (auto& r : P.rawTok) if (r.fz && !r.fz->materialised) {
-            if (B.unionIdx.emplace(r.fz.get(), (uint32_t)B.pending.size()).second) B.pending.push_back(r.fz);
+            auto it = byWord.find(r.text);
+            uint32_t v;
+            if (it == byWord.end()) { v = (uint32_t)B.pending.size(); byWord.emplace(r.text, v); B.pending.push_back(r.fz); } else v = it->second;
+            B.unionIdx.emplace(r.fz.get(), v);
         }
         B.pendingCounts.assign(B.pending.size(), 0);
         std::vector<uint32_t> mo(B.pending.size() + 1, 0); std::vector<int32_t> mm;
@@ -284,6 +291,7 @@ static int32_t ph_plan_finish(infx_engine* e, infx_session* S, const uint32_t* g
     Batch& B = *S->batch; const uint32_t nq = B.nq;
     std::vector<QueryPlan>& plans = S->lastPlans;
     for (size_t v = 0; v < B.pending.size(); v++) B.pending[v]->df.store((int)globalUnionCounts[v]);
+    for (auto& kv : B.unionIdx) const_cast<FuzzyUnion*>(kv.first)->df.store((int)globalUnionCounts[kv.second]);      // every object of the word, not only the first
     parallel_dyn(nq, threads, 8, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; i++) plan_finish(ix, plans[i]); });
     B.tPlanPar = now_ms() - B.t0;
     const int32_t sb = e->shardBase, se = e->shardBase + e->shardN;
@@ -1363,6 +1371,7 @@ static uint64_t syn_hash(const SynMap& m) {
     for (auto& pr : m.parent) for (const ustr* t : {&pr.first, &pr.second}) { for (u16 c : *t) { h ^= c; h *= 1099511628211ull; } h ^= 0xFFFFu; h *= 1099511628211ull; }
     return h;
 }
+int64_t infx_engine_fuzzy_cache_size(infx_engine* e) { return e ? (int64_t)e->fuzzy.size() : -1; }
 int32_t infx_engine_set_build_threads(infx_engine* e, int32_t threads) {
     if (!e || threads < 0) return efail(INFX_EINVAL, "bad arguments");
     e->buildThreads = threads; return INFX_OK;

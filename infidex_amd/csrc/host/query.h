@@ -10,6 +10,7 @@
 #pragma once
 #include "index.h"
 #include "../../../include/infidex_hip.h"
+#include <list>
 #include <mutex>
 #include <unordered_map>
 #include <memory>
@@ -213,12 +214,27 @@ struct FuzzyUnion {
 constexpr size_t FUZZY_MAX_MEMBERS = 512;
 struct FuzzyCache {
     std::atomic<long long> fuzzyNs{0}, fuzzyCalls{0}, fuzzyDocs{0}, ld1Ns{0};   // instrumentation (INFX_DEBUG)
-    std::mutex mu; std::unordered_map<std::u16string, std::shared_ptr<FuzzyUnion>> map;
-    std::shared_ptr<FuzzyUnion> get(const ustr& k) { std::lock_guard<std::mutex> l(mu); auto it = map.find(k); return it == map.end() ? nullptr : it->second; }
-    std::shared_ptr<FuzzyUnion> put(const ustr& k, std::shared_ptr<FuzzyUnion> v) {   // first writer wins
-        std::lock_guard<std::mutex> l(mu); if (map.size() > 100000) map.clear();
-        auto r = map.emplace(k, v); return r.first->second;
+    // least-recently-used, 1000 expansions — the reference's _fuzzyExpansionCache (VectorModel.cs:42, LruCache :745-800): a larger cache would let a long
+    // query stream plan warmer than the reference can.  Entries are shared_ptr: a batch in flight keeps the unions it planned with after their eviction.
+    static constexpr size_t CAPACITY = 1000;
+    typedef std::list<std::pair<std::u16string, std::shared_ptr<FuzzyUnion>>> Order;     // front = most recently used
+    std::mutex mu; Order order; std::unordered_map<std::u16string, Order::iterator> map;
+    std::shared_ptr<FuzzyUnion> get(const ustr& k) {
+        std::lock_guard<std::mutex> l(mu);
+        auto it = map.find(k);
+        if (it == map.end()) return nullptr;
+        order.splice(order.begin(), order, it->second);
+        return it->second->second;
     }
+    std::shared_ptr<FuzzyUnion> put(const ustr& k, std::shared_ptr<FuzzyUnion> v) {   // first writer wins (two planner threads may expand the same word)
+        std::lock_guard<std::mutex> l(mu);
+        auto it = map.find(k);
+        if (it != map.end()) { order.splice(order.begin(), order, it->second); return it->second->second; }
+        if (map.size() >= CAPACITY) { map.erase(order.back().first); order.pop_back(); }
+        order.emplace_front(k, v); map.emplace(k, order.begin());
+        return v;
+    }
+    size_t size() { std::lock_guard<std::mutex> l(mu); return map.size(); }
 };
 inline void materialise_union(const HostIndex& ix, FuzzyUnion& fz) {    // union of the (sorted) member lists: pairwise merges, smallest first
     std::vector<std::pair<const int32_t*, size_t>> lists;

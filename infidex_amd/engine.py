@@ -348,6 +348,11 @@ class SearchEngine:
                 "mode": int(meta[0]), "prefix_set": int(meta[1]), "n_and": int(meta[2]), "df_s1": int(meta[3]), "df_s2": int(meta[4]),
                 "flags": flags.value}
 
+    def fuzzy_cache_size(self) -> int:
+        """Entries of the LD1 expansion cache (LRU, at most 1000 like the reference's)."""
+        self.L.infx_engine_fuzzy_cache_size.restype = C.c_int64
+        return int(self.L.infx_engine_fuzzy_cache_size(self.h))
+
     def wordmatcher(self, text, cap=1 << 22):
         a = _u16(text); out = np.zeros(cap, np.int32)
         n = self.L.infx_engine_wordmatcher(self.h, _p(a, C.c_uint16), len(a), _p(out, C.c_int32), C.c_int64(cap))

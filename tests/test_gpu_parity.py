@@ -450,3 +450,35 @@ np.savez(sys.argv[1], **out)
         for key in res[0].files:
             assert np.array_equal(res[0][key], other[key]), key
     assert res[0]["plain_s1k"].size > 1000
+
+
+def test_expansion_cache_eviction_inside_a_batch():
+    """More than 1000 distinct misspelt words in ONE batch, the first queries repeated at its end: by then the LRU expansion cache (1000 entries, as the
+    reference's) has evicted their words, so two queries of the batch hold different union objects for one word.  The batch still builds ONE device
+    union per word, in the same order on every shard (its cardinality is all-reduced position by position), and the rows are the oracle's — on one GPU
+    and on two document shards."""
+    from infidex_amd.sharded import create_sharded_engine, ShardSession, simulate_shards
+    from infidex_amd.engine import pack_texts
+    from tests.parity_classify import assert_final_rows_match_oracle
+    s = Synth(2, docs=70000)
+    arena, offs = s.docs()
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    qa, qo = s.queries(1150, qseed=61, fuzz=1.0)
+    qs = Synth.texts(qa, qo)
+    qs = qs + qs[:60]
+    a2, o2 = pack_texts(qs)
+    e = SearchEngine.create_default(device=0); e.index_flat(None, arena, offs, s.field_weights)
+    k, sc, t, c, f = e.search_packed(a2, o2, 10)
+    assert e.fuzzy_cache_size() == 1000                       # the batch overflowed the cache
+    same, flips = assert_final_rows_match_oracle(k, sc, c, o, qs, 10, what="one GPU")
+    assert np.array_equal(k[:60], k[-60:]) and np.array_equal(c[:60], c[-60:])      # a repeated query gets the rows of its first occurrence
+    W = 2
+    engs = [create_sharded_engine(r, W, 0) for r in range(W)]
+    for g in engs:
+        g.index_flat(None, arena, offs, s.field_weights)
+    sess = [ShardSession(g) for g in engs]
+    host = simulate_shards(sess, a2, o2, 10)
+    for r in host[1:]:
+        for x, y in zip(r, host[0]):
+            assert np.array_equal(x, y)
+    assert np.array_equal(host[0][0], k) and np.array_equal(host[0][3], c)

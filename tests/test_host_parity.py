@@ -281,3 +281,24 @@ def test_host_plan_profile_hook_reports_every_stage():
     out = np.zeros(8, np.float64)
     assert e.L.infx_engine_host_plan_profile(e.h, 200, _p(qa, C.c_uint16), _p(qo, C.c_uint64), 500, _p(out, C.c_double)) == 0
     assert all(out[i] > 0 for i in (0, 2, 3, 4)) and 0 < out[1] <= out[0] and out[:5].sum() < 5000
+
+
+def test_expansion_cache_is_the_references_lru_1000():
+    """VectorModel.cs:42: _fuzzyExpansionCache = LruCache(1000).  The product's cache holds at most 1000 expansions, evicts the least recently used one,
+    and a plan does not depend on whether its words were cached."""
+    s = Synth(2, docs=20000)
+    arena, offs = s.docs()
+    e = SearchEngine.create_default(device=-1, threads=2)
+    e.index_flat(None, arena, offs, s.field_weights)
+    qa, qo = s.queries(1400, qseed=77, fuzz=1.0)
+    texts = Synth.texts(qa, qo)
+    first = [e.plan(t) for t in texts[:40]]
+    assert 0 < e.fuzzy_cache_size() <= 1000
+    for t in texts[40:]:
+        e.plan(t)
+    assert e.fuzzy_cache_size() == 1000                       # more than 1000 distinct misspelt words went through: full, not larger
+    again = [e.plan(t) for t in texts[:40]]                   # their expansions were evicted long ago
+    for a, b in zip(first, again):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    assert e.fuzzy_cache_size() == 1000
