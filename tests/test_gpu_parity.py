@@ -463,7 +463,7 @@ def test_expansion_cache_eviction_inside_a_batch():
     s = Synth(2, docs=70000)
     arena, offs = s.docs()
     o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
-    qa, qo = s.queries(1150, qseed=61, fuzz=1.0)
+    qa, qo = s.queries(1500, qseed=61, fuzz=1.0)           # ~1 230 distinct misspelt words
     qs = Synth.texts(qa, qo)
     qs = qs + qs[:60]
     a2, o2 = pack_texts(qs)
