@@ -1248,6 +1248,7 @@ int32_t infx_engine_term_text(infx_engine* e, int32_t t, uint16_t* out, int32_t 
     return (int32_t)s.size();
 }
 int32_t infx_engine_match_ld1(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int32_t cap) {
+    if (!e || len < 0 || (len && !q) || (cap > 0 && !out)) return -1;
     std::vector<int> m; int c = match_ld1(e->ix, uview((const u16*)q, len), m, cap);
     for (size_t i = 0; i < m.size(); i++) out[i] = m[i];
     return c;
@@ -1298,6 +1299,7 @@ int32_t infx_engine_host_plan_profile(infx_engine* e, uint32_t nq, const uint16_
 }
 // WordMatcherLookup.Execute, fully enumerated (tests only): sorted unique ids
 int64_t infx_engine_wordmatcher(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int64_t cap) {
+    if (!e || len < 0 || (len && !q) || (cap > 0 && !out)) return -1;
     WmResult wm; ustr t = normalize(uview((const u16*)q, len)); lower_inplace(t);
     wm_collect(e->ix, t, true, wm);
     std::vector<int32_t> all;
@@ -1307,6 +1309,7 @@ int64_t infx_engine_wordmatcher(infx_engine* e, const uint16_t* q, int32_t len, 
     return (int64_t)all.size();
 }
 int32_t infx_engine_prefix_pop(infx_engine* e, const uint16_t* p, int32_t len) {
+    if (!e || len < 0 || (len && !p)) return -1;
     int64_t k = e->ix.prefixKeys.find(uview((const u16*)p, len)); return k < 0 ? 0 : (int32_t)e->ix.prefixPop[k];
 }
 // last batch: Stage-1 hits of query i (device order re-sorted to the reference's) and the Stage-2 records
@@ -1474,7 +1477,7 @@ int32_t infx_engine_add_column(infx_engine* e, const char* name, int32_t kind, i
     e->retire_filters();      // leaf tables of filters compiled before this field existed treat it as null: compile again on next use
     return INFX_OK;
 }
-int32_t infx_engine_column_count(infx_engine* e) { return e ? (int32_t)e->columns.size() : 0; }
+int32_t infx_engine_column_count(infx_engine* e) { return e ? (int32_t)e->columns.size() : -1; }
 int32_t infx_engine_column_info(infx_engine* e, int32_t col, char* name, int32_t cap, int32_t* facetable, int32_t* num_values) {
     if (!e || col < 0 || col >= (int32_t)e->columns.size()) return INFX_EINVAL;
     const filt::Column& c = e->columns[col];
@@ -1549,6 +1552,6 @@ int32_t infx_engine_last_facets(infx_session* S, uint32_t nq, uint32_t qi, uint3
     int32_t m = 0; for (auto& x : v) { if (m >= cap) break; codes[m] = x.first; counts[m] = x.second; m++; }
     return m;
 }
-int32_t infx_engine_facet_column_count(infx_session* S) { return S ? (int32_t)S->facetCols.size() : 0; }
+int32_t infx_engine_facet_column_count(infx_session* S) { return S ? (int32_t)S->facetCols.size() : -1; }
 
 } // extern "C"
