@@ -107,6 +107,7 @@ int32_t infx_stream_scratch(infx_stream* s, int32_t slot, uint64_t bytes, void**
 int32_t infx_stream_copy(infx_stream* s, void* dst, const void* src, uint64_t bytes);      /* stream-ordered; host pointers are staged; call infx_stream_wait before reading a host destination */
 int32_t infx_stream_fill0(infx_stream* s, void* dev, uint64_t bytes);
 int32_t infx_stream_wait(infx_stream* s);
+int32_t infx_stream_native(infx_stream* s, void** hip_stream);      /* the hipStream_t the stream's kernels, copies and collectives are ordered on */
 
 int32_t infx_stream_create(infx_index* idx, infx_stream** out);
 void    infx_stream_destroy(infx_stream* s);

@@ -1038,6 +1038,8 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
     if (comm->nranks != e->nranks || comm->rank != e->rank) return efail(INFX_EINVAL, "communicator and engine disagree about the shard layout");
     const int W = comm->nranks; const bool dev = comm->device_buffers != 0;
     void* const cctx = comm->ctx ? comm->ctx : (void*)S->stream;       // the in-library RCCL ops run on the session's stream
+    void* hs = nullptr;                                                // what a caller-supplied op with device buffers orders itself on: the session's hipStream_t
+    if (dev && infx_stream_native(S->stream, &hs) != INFX_OK) return efail(INFX_EINVAL, "device exchange buffers need a session with a GPU stream");
     auto chk = [&](int32_t rc) { if (rc && g_eerr.empty()) g_eerr = infx_last_error(); return rc; };
 #define XCHK(x) do { int32_t rc_ = chk(x); if (rc_) return rc_; } while (0)
     XBufs X(S, dev);
@@ -1048,22 +1050,22 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
         if (dev) {
             void* d = nullptr; XCHK(X.get(guc.size() * 4, &d, false));
             XCHK(infx_stream_copy(S->stream, d, guc.data(), guc.size() * 4));
-            XCHK(comm->allreduce_sum_u32(cctx, d, guc.size(), nullptr));
+            XCHK(comm->allreduce_sum_u32(cctx, d, guc.size(), hs));
             XCHK(infx_stream_copy(S->stream, guc.data(), d, guc.size() * 4)); XCHK(infx_stream_wait(S->stream));
-        } else XCHK(comm->allreduce_sum_u32(cctx, guc.data(), guc.size(), nullptr));
+        } else XCHK(comm->allreduce_sum_u32(cctx, guc.data(), guc.size(), hs));
     }
     static const uint32_t zero = 0;
     // phase 1 + Exchange 1: class histograms (tier decisions need GLOBAL cardinalities, Q11)
     void* counts = nullptr; XCHK(X.get((size_t)std::max<uint32_t>(nq, 1) * INFX_NCLASS * 4, &counts, true));
     uint32_t nd = 0; XCHK(infx_session_phase1x(S, guc.empty() ? &zero : guc.data(), counts, &nd));
-    XCHK(comm->allreduce_sum_u32(cctx, counts, (uint64_t)std::max<uint32_t>(nq, 1) * INFX_NCLASS, nullptr));
+    XCHK(comm->allreduce_sum_u32(cctx, counts, (uint64_t)std::max<uint32_t>(nq, 1) * INFX_NCLASS, hs));
     // phase 2a + Exchange 2a: first-pass lists, counts, best score left out
     const size_t ndp = std::max<uint32_t>(nd, 1), hitB = ndp * depth * sizeof(infx_hit);
     void *hits = nullptr, *hc = nullptr, *nxt = nullptr, *ah = nullptr, *ac = nullptr, *an = nullptr;
     XCHK(X.get(hitB, &hits, true)); XCHK(X.get(ndp * 4, &hc, true)); XCHK(X.get(ndp * 4, &nxt, true));
     XCHK(X.get(hitB * W, &ah, false)); XCHK(X.get(ndp * 4 * W, &ac, false)); XCHK(X.get(ndp * 4 * W, &an, false));
     XCHK(infx_session_phase2a(S, counts, hits, hc, nxt));
-    XCHK(comm->allgather(cctx, hits, ah, hitB, nullptr)); XCHK(comm->allgather(cctx, hc, ac, ndp * 4, nullptr)); XCHK(comm->allgather(cctx, nxt, an, ndp * 4, nullptr));
+    XCHK(comm->allgather(cctx, hits, ah, hitB, hs)); XCHK(comm->allgather(cctx, hc, ac, ndp * 4, hs)); XCHK(comm->allgather(cctx, nxt, an, ndp * 4, hs));
     // phase 2b + Exchange 2c: this shard's part of the exact replay, packed; padded to the largest blob of the world
     uint64_t blobBytes = 0; XCHK(infx_session_phase2b(S, W, ah, ac, an, &blobBytes));
     uint64_t pad = blobBytes;
@@ -1072,17 +1074,17 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
         if (dev) {
             void* d = nullptr; XCHK(X.get(sz.size() * 4, &d, false));
             XCHK(infx_stream_copy(S->stream, d, sz.data(), sz.size() * 4));
-            XCHK(comm->allreduce_sum_u32(cctx, d, sz.size(), nullptr));
+            XCHK(comm->allreduce_sum_u32(cctx, d, sz.size(), hs));
             XCHK(infx_stream_copy(S->stream, sz.data(), d, sz.size() * 4)); XCHK(infx_stream_wait(S->stream));
-        } else XCHK(comm->allreduce_sum_u32(cctx, sz.data(), sz.size(), nullptr));
+        } else XCHK(comm->allreduce_sum_u32(cctx, sz.data(), sz.size(), hs));
         pad = 16ull * *std::max_element(sz.begin(), sz.end());
     }
     void *blob = nullptr, *ab = nullptr; XCHK(X.get(pad, &blob, false)); XCHK(X.get(pad * W, &ab, false));
     XCHK(infx_session_phase2b_blob(S, blob, pad));
-    XCHK(comm->allgather(cctx, blob, ab, pad, nullptr));
+    XCHK(comm->allgather(cctx, blob, ab, pad, hs));
     // phase 2c + Exchange 2b: owner-side heap; the all-gather of the per-rank final lists
     XCHK(infx_session_phase2c(S, W, ab, pad, hits, hc));
-    XCHK(comm->allgather(cctx, hits, ah, hitB, nullptr)); XCHK(comm->allgather(cctx, hc, ac, ndp * 4, nullptr));
+    XCHK(comm->allgather(cctx, hits, ah, hitB, hs)); XCHK(comm->allgather(cctx, hc, ac, ndp * 4, hs));
     // queries the parallel replay could not certify (rare): the literal sequential replay, shard after shard
     std::vector<uint32_t> fc((size_t)W * ndp);
     XCHK(infx_stream_copy(S->stream, fc.data(), ac, fc.size() * 4)); XCHK(infx_stream_wait(S->stream));
@@ -1096,9 +1098,9 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
         for (int r = 0; r < W; r++) {
             if (r == comm->rank) XCHK(infx_session_phase2d(S, need.data(), state.data()));
             if (dev) {
-                XCHK(infx_stream_copy(S->stream, ds, state.data(), words * 4)); XCHK(comm->allgather(cctx, ds, da, words * 4, nullptr));
+                XCHK(infx_stream_copy(S->stream, ds, state.data(), words * 4)); XCHK(comm->allgather(cctx, ds, da, words * 4, hs));
                 XCHK(infx_stream_copy(S->stream, all.data(), da, words * 4 * W)); XCHK(infx_stream_wait(S->stream));
-            } else XCHK(comm->allgather(cctx, state.data(), all.data(), words * 4, nullptr));
+            } else XCHK(comm->allgather(cctx, state.data(), all.data(), words * 4, hs));
             std::memcpy(state.data(), all.data() + (size_t)r * words, words * 4);          // rank r's continuation is the state of record
         }
         std::vector<infx_hit> fh((size_t)W * ndp * depth);
@@ -1115,7 +1117,7 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
     // phase 3 + the all-reduce of the disjoint Stage-2 rows + phase 4
     void* outs = nullptr; XCHK(X.get((size_t)std::max<uint32_t>(nq, 1) * 2 * depth * sizeof(infx_cov_out), &outs, true));
     XCHK(infx_session_phase3x(S, W, ah, ac, max_results, enable_coverage, outs));
-    XCHK(comm->allreduce_sum_u32(cctx, outs, (uint64_t)std::max<uint32_t>(nq, 1) * 2 * depth * 3, nullptr));
+    XCHK(comm->allreduce_sum_u32(cctx, outs, (uint64_t)std::max<uint32_t>(nq, 1) * 2 * depth * 3, hs));
     XCHK(infx_session_phase4(S, (const int32_t*)outs, out_keys, out_scores, out_ties, out_counts, out_flags));
 #undef XCHK
     return INFX_OK;

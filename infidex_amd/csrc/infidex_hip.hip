@@ -841,6 +841,11 @@ int32_t infx_stream_wait(infx_stream* s) {
     return stream_sync(s);
 }
 
+int32_t infx_stream_native(infx_stream* s, void** hip_stream) {
+    if (!s || !hip_stream) return fail(INFX_EINVAL, "null argument%s");
+    *hip_stream = (void*)s->st; return INFX_OK;
+}
+
 int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     if (!ix || !out) return fail(INFX_EINVAL, "null argument%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
