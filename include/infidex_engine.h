@@ -143,6 +143,13 @@ int32_t infx_engine_match_ld1_forward(infx_engine* e, const uint16_t* q, int32_t
 int32_t infx_engine_plan(infx_engine* e, const uint16_t* q, int32_t len, int32_t depth, int32_t* term_ids, int32_t* dfs, float* idfs,
                          uint8_t* roles, uint8_t* ranks, int32_t cap, int32_t* meta5, int32_t* flags);
 int64_t infx_engine_wordmatcher(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int64_t cap);
+/* The LD1 / WordMatcher lookups of planning as the DEVICE answers them (infidex_hip.h "Dictionary lookups"; uploaded by IndexDocuments unless
+ * INFX_HOST_LOOKUPS=1).  _match_ld1_device: like _match_ld1 (count, first `cap` term ids in ordinal order); -1 / -2 = the kernel handed the word back to the
+ * host (work lists outgrown / length outside 1..64).  _wordmatcher_device: like _wordmatcher (ascending unique doc ids over all of the query's lists). */
+int32_t infx_engine_device_lookups(infx_engine* e);
+int32_t infx_engine_lookup_stats(infx_engine* e, int64_t* out4 /* LD1 words on device / on host, WordMatcher queries on device / on host */);
+int32_t infx_engine_match_ld1_device(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int32_t cap);
+int64_t infx_engine_wordmatcher_device(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int64_t cap);
 int32_t infx_engine_prefix_pop(infx_engine* e, const uint16_t* p, int32_t len);
 int32_t infx_engine_last_stage1(infx_engine* e, uint32_t qi, int64_t* keys, float* scores, int32_t cap);
 int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* docs, float* base, float* scores, uint8_t* ties,

@@ -263,18 +263,49 @@ typedef struct infx_wm_list {      /* one ascending doc-id list */
     uint64_t off;
 } infx_wm_list;
 
+/* ---- Dictionary lookups of query planning on the device ------------------------------------------------------------
+ * The reference resolves a query word to doc-id lists through three host dictionaries; uploaded once, the lookups run on the GPU:
+ *   - WordMatcher.Lookup (WordMatcher/WordMatcher.cs:201-246): the word in the exact-word dictionary; for words of min_ld1..max_ld1 characters the word
+ *     and each of its single-character deletions in the symmetric-delete dictionary and the exact dictionary;
+ *   - WordMatcher.LookupAffix (:277-354): the words the query word is a prefix of, then those it is a suffix of — at most 4096 trie terms in that
+ *     order — each contributing the LAST document that contains it (quirk Q13);
+ *   - FstIndex.MatchWithinEditDistance1 (Indexing/Fst/FstIndex.cs:202-351): index terms with a suffix within Levenshtein distance 1 of the word.
+ * Keys are UTF-16 strings in one arena per dictionary (key k = chars[key_offs[k] .. key_offs[k+1])); the library builds its own hash tables.
+ * exact/ld1 list_offs index the doc-id arrays handed to infx_upload_wordmatcher (call that first).  affix_fwd / affix_rev: ids of the words of at
+ * least min_ld1 characters, in ordinal order of the word / of the reversed word (the order the reference's trie walk meets them in). */
+int32_t infx_upload_wm_dictionary(infx_index* idx,
+                                  uint32_t n_exact_keys, const uint32_t* exact_key_offs /* n+1 */, const uint16_t* exact_chars, const uint64_t* exact_list_offs /* n+1 */,
+                                  uint32_t n_ld1_keys, const uint32_t* ld1_key_offs, const uint16_t* ld1_chars, const uint64_t* ld1_list_offs,
+                                  uint32_t n_words, const uint32_t* word_offs /* n+1 */, const uint16_t* word_chars, const int32_t* word_last_doc,
+                                  uint32_t n_affix, const uint32_t* affix_fwd, const uint32_t* affix_rev, int32_t min_ld1, int32_t max_ld1);
+/* Trie of the REVERSED index terms as CSR (node 0 = root; children of node v = edges edge_start[v] .. edge_start[v+1), ascending label), node_term[v] =
+ * term id ending at v or -1; sorted_terms = all term ids in ordinal order of their text (FstIndex returns matches in that order). */
+int32_t infx_upload_term_trie(infx_index* idx, uint32_t n_nodes, const uint32_t* edge_start /* n_nodes+1 */, const uint16_t* edge_label, const uint32_t* edge_child,
+                              const int32_t* node_term, uint32_t n_terms, const uint32_t* sorted_terms);
+/* FstIndex.MatchWithinEditDistance1 for a batch of words (word w = chars[word_offs[w] .. word_offs[w+1])): counts_out[w] = number of matching terms,
+ * members_out[w*cap ..] = the first min(count, cap) of them in ordinal order (the reference keeps the first 1024, VectorModel.cs:660).
+ * status_out[w]: 0 ok; 1 the walk outgrew the kernel's work lists (very short words fan out over the whole vocabulary) and 2 word length outside 1..64
+ * (the reference switches to another walk, FstIndex.cs:362-440) — in both cases nothing was written for w and the caller expands it on the host. */
+int32_t infx_ld1_expand(infx_stream* s, uint32_t nwords, const uint32_t* word_offs /* n+1 */, const uint16_t* chars, uint32_t cap,
+                        int32_t* members_out /* nwords x cap */, uint32_t* counts_out, uint32_t* status_out);
+/* WordMatcher lists of ONE coverage query as the device produces them (parity tests): lists_out[INFX_MAX_WM_LISTS], *nlists_out of them; src 2 offsets
+ * index owned_out (owned_cap ints, >= 4096 per word of the query). */
+int32_t infx_wm_lookup_debug(infx_stream* s, const infx_cov_query* cq, infx_wm_list* lists_out, uint32_t* nlists_out, int32_t* owned_out, uint64_t owned_cap);
+
 #define INFX_FQ_SKIP 1u            /* blank / unsupported query text: empty result */
 #define INFX_FQ_SHORT 2u           /* 1..3 characters without delimiter (SearchPipeline.cs:108-120) */
 #define INFX_FQ_SHORTSKIP 4u       /* short query whose prefix population exceeds 500: coverage is skipped */
 #define INFX_FQ_COV 8u             /* coverage enabled (engine setup && Query.EnableCoverage) */
 #define INFX_FQ_UNSUPPORTED 16u    /* result flag bit0 is set */
+#define INFX_FQ_WMDEV 32u          /* the WordMatcher lists of this query are looked up on the device (infx_upload_wm_dictionary) from the words of its
+                                      infx_cov_query; wm_off / wm_count are ignored (leave wm_count 0).  Admissible while words x (3 + 2*max_ld1) <= INFX_MAX_WM_LISTS */
 #define INFX_MAX_WM_LISTS 256
 typedef struct infx_fused_query {
     int32_t  dev;                  /* index into q[] of the Stage-1 part, or -1 (no index term) */
     uint32_t flags;                /* INFX_FQ_* */
     uint32_t wm_off, wm_count;     /* lists[wm_off .. +wm_count), non-empty lists only, <= INFX_MAX_WM_LISTS */
     int32_t  max_results;          /* Query.MaxNumberOfRecordsToReturn */
-    int32_t  reserved;
+    int32_t  reserved;             /* set by the library */
 } infx_fused_query;
 
 /* nd Stage-1 queries q[] (+ terms), nq search queries fq[]/cq[] (nq >= nd; cq[i] is ignored unless coverage runs for i).

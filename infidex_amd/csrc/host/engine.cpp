@@ -100,6 +100,8 @@ struct infx_engine {
     std::unordered_map<int64_t, int32_t> keyToFirst;
     bool keysAreIds = false;
     std::vector<uint8_t> deleted;     // Document.Deleted per global internal id; empty = nothing deleted
+    std::atomic<long long> ld1OnHost{0}, ld1OnDevice{0}, wmOnHost{0}, wmOnDevice{0};      // where the planning lookups ran (introspection)
+    bool devLookups = false;          // WordMatcher dictionaries + term trie uploaded: the LD1 / WordMatcher lookups of planning run on the GPU (f3)
     int threads = 1;
     int buildThreads = 0;             // > 0: threads of the index build only (infx_engine_set_build_threads)
     infx_session* def = nullptr;      // default session (single-caller API)
@@ -179,6 +181,38 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
     return finish_index(e);
 }
 
+
+// The dictionaries of the planning lookups go to the device next to the lists they resolve to (include/infidex_hip.h "Dictionary lookups"): WordMatcher
+// exact / symmetric-delete keys, the word list with its affix orders, the reversed-term trie.  INFX_HOST_LOOKUPS=1 keeps the lookups on the host.
+static void key_arena(const KeyTable& K, std::vector<uint32_t>& offs, std::vector<u16>& repack, const u16*& chars) {
+    const size_t n = K.size();
+    offs.resize(n + 1);
+    bool contiguous = true; uint32_t run = n ? K.keyOff[0] : 0;
+    for (size_t i = 0; i < n; i++) { if (K.keyOff[i] != run) { contiguous = false; break; } run += K.keyLen[i]; }
+    if (contiguous && (n == 0 || K.keyOff[0] == 0)) { for (size_t i = 0; i < n; i++) offs[i] = K.keyOff[i]; offs[n] = run; chars = K.arena.data(); return; }
+    repack.clear(); for (size_t i = 0; i < n; i++) { offs[i] = (uint32_t)repack.size(); repack.insert(repack.end(), K.arena.begin() + K.keyOff[i], K.arena.begin() + K.keyOff[i] + K.keyLen[i]); }
+    offs[n] = (uint32_t)repack.size(); chars = repack.data();
+}
+static int32_t upload_lookups(infx_engine* e) {
+    const HostIndex& ix = e->ix;
+    { const char* h = getenv("INFX_HOST_LOOKUPS"); if (h && h[0] == '1') return INFX_OK; }
+    if (ix.rEdgeStart.size() < 2) return INFX_OK;
+    int32_t rc = infx_upload_term_trie(e->dev, (uint32_t)ix.rTerm.size(), ix.rEdgeStart.data(), (const uint16_t*)ix.rEdgeLabel.data(), ix.rEdgeChild.data(), ix.rTerm.data(),
+                                       (uint32_t)ix.sortedTerms.size(), ix.sortedTerms.data());
+    if (rc) return rc;
+    if (ix.cfg.wordMatcher) {
+        std::vector<uint32_t> eo, lo, wo; std::vector<u16> er, lr, wr; const u16 *ec = nullptr, *lc = nullptr, *wc = nullptr;
+        key_arena(ix.wmExact.keys, eo, er, ec); key_arena(ix.wmLd1.keys, lo, lr, lc); key_arena(ix.words, wo, wr, wc);
+        rc = infx_upload_wm_dictionary(e->dev, (uint32_t)ix.wmExact.K(), eo.data(), (const uint16_t*)ec, ix.wmExact.off.data(),
+                                       (uint32_t)ix.wmLd1.K(), lo.data(), (const uint16_t*)lc, ix.wmLd1.off.data(),
+                                       (uint32_t)ix.words.size(), wo.data(), (const uint16_t*)wc, ix.wordLastDoc.data(),
+                                       (uint32_t)ix.affixFwd.size(), ix.affixFwd.data(), ix.affixRev.data(), ix.cfg.wmMinLD1, ix.cfg.wmMaxLD1);
+        if (rc) return rc;
+    }
+    e->devLookups = true;
+    return INFX_OK;
+}
+
 // After the host index exists (built here or read from a node-local cache): key map, shard bounds, upload of this rank's slice
 static int32_t finish_index(infx_engine* e) {
     if (!e->keysAreIds) { const int64_t n = e->ix.N; e->keyToFirst.reserve((size_t)n * 2); for (int64_t d = 0; d < n; d++) e->keyToFirst.emplace(e->ix.docKey[d], (int32_t)d); }
@@ -231,6 +265,7 @@ static int32_t finish_index(infx_engine* e) {
             if (!rc && ix.cfg.wordMatcher) rc = infx_upload_wordmatcher(e->dev, ix.wmExact.doc.size(), ix.wmExact.doc.data(), ix.wmLd1.doc.size(), ix.wmLd1.doc.data());
             if (!rc) rc = infx_upload_doc_keys_all(e->dev, (uint32_t)ix.N, ix.docKey.data());
         }
+        if (!rc) rc = upload_lookups(e);
         if (!rc) rc = infx_stream_create(e->dev, &e->def->stream);
         if (rc) { g_eerr = infx_last_error(); return rc; }
     }
@@ -249,6 +284,37 @@ static int32_t key_to_id(infx_engine* e, int64_t key) {
 // One batch = four phases.  Unsharded: they run back to back (search_batch_impl).  Document-sharded: the caller
 // (infidex_amd/sharded.py) interleaves the collectives — all-reduce of the class histograms after phase 1, all-gather of the
 // per-shard top-`depth` after phase 2, all-reduce of the disjoint Stage-2 records after phase 3.
+
+// FstIndex.MatchWithinEditDistance1 for the distinct unknown words of a batch that the expansion cache does not hold: one infx_ld1_expand call; the few
+// words the kernel hands back (work lists outgrown, longer than 64 characters) are expanded by the host walk.  Results enter the LRU cache as before.
+static int32_t expand_pending(infx_engine* e, infx_session* S, std::vector<QueryPlan>& plans) {
+    const HostIndex& ix = e->ix;
+    std::vector<const ustr*> words; std::unordered_map<std::u16string, uint32_t> idx;
+    for (auto& P : plans) for (auto& r : P.rawTok) if (r.pending && idx.emplace(r.text, (uint32_t)words.size()).second) words.push_back(&r.text);
+    if (words.empty()) return INFX_OK;
+    const uint32_t nw = (uint32_t)words.size(), cap = 1024;
+    std::vector<std::shared_ptr<FuzzyUnion>> made(nw);
+    std::vector<uint32_t> offs(nw + 1, 0), counts(nw, 0), status(nw, 2); std::vector<u16> chars; std::vector<int32_t> members((size_t)nw * cap);
+    for (uint32_t i = 0; i < nw; i++) { if (words[i]->size() <= 64) chars.insert(chars.end(), words[i]->begin(), words[i]->end()); offs[i + 1] = (uint32_t)chars.size(); }     // longer words: empty -> status 2
+    auto t0 = std::chrono::steady_clock::now();
+    int32_t rc = infx_ld1_expand(S->stream, nw, offs.data(), (const uint16_t*)chars.data(), cap, members.data(), counts.data(), status.data());
+    if (rc) { g_eerr = infx_last_error(); return rc; }
+    std::vector<uint32_t> onHost;
+    for (uint32_t i = 0; i < nw; i++) {
+        if (status[i] == 0) made[i] = union_of_matches(ix, members.data() + (size_t)i * cap, std::min(counts[i], cap));
+        else onHost.push_back(i);
+    }
+    if (!onHost.empty())
+        parallel_dyn((int64_t)onHost.size(), e->threads, 1, [&](int64_t b, int64_t en, int) {
+            std::vector<int> m;
+            for (int64_t k = b; k < en; k++) { const uint32_t i = onHost[k]; match_ld1(ix, *words[i], m, (int)cap); made[i] = union_of_matches(ix, m.data(), m.size()); }
+        });
+    e->fuzzy.ld1Ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    e->fuzzy.fuzzyCalls += nw; e->ld1OnHost += (long long)onHost.size(); e->ld1OnDevice += (long long)(nw - onHost.size());
+    for (uint32_t i = 0; i < nw; i++) made[i] = e->fuzzy.put(*words[i], made[i]);
+    for (auto& P : plans) for (auto& r : P.rawTok) if (r.pending) { r.fz = made[idx.at(r.text)]; r.pending = false; }
+    return INFX_OK;
+}
 static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth) {
     if (!e || (nq && (!q_arena || !q_offs))) return efail(INFX_EINVAL, "bad arguments");
     if (!e->dev || !S || !S->stream) return efail(INFX_EHIP, "no GPU: the scoring hot path has no CPU fallback");
@@ -258,9 +324,11 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
     g_eerr.clear();
     B.t0 = now_ms();
     std::vector<QueryPlan>& plans = S->lastPlans; plans.assign(nq, QueryPlan());
-    parallel_dyn(nq, threads, 1, [&](int64_t b, int64_t en, int) {
-        for (int64_t i = b; i < en; i++) plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i], false);
+    const bool devLd1 = e->devLookups;
+    parallel_dyn(nq, threads, devLd1 ? 8 : 1, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; i++) plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i], false, devLd1);
     });
+    if (devLd1) { int32_t rc = expand_pending(e, S, plans); if (rc) return rc; }
     B.tTok = now_ms() - B.t0;
     {   // every fuzzy union this batch uses is materialised on the device (this shard's slice); |union| = its df (sharded:
         // summed over the shards by the caller)
@@ -625,6 +693,20 @@ static void wm_descriptors(const HostIndex& ix, const ustr& st, WmResult& wm, st
         lists.assign(1, L);
     }
 }
+
+// May k_wm look this query's words up?  It reads them from the coverage query text as they stand, where WordMatcherLookup normalises each word again
+// (lower + Normalize, WordMatcherLookup.cs:27-31) — the identity on an already prepared search text, checked here; and a query may hold at most
+// INFX_MAX_WM_LISTS lists (each word: <= 2 + 2*maxLd1 dictionary hits + 1 affix list).
+static bool wm_on_device(const HostIndex& ix, const ustr& st) {
+    const auto& T = tables();
+    int words = 0; bool same = true;
+    for_each_word(st, [&](int off, int len) {
+        if (len < 2) return;
+        words++;
+        for (int i = 0; i < len; i++) { const u16 c = st[off + i]; const u16 n = T.norm[T.lower[c]]; if (n != c || n == u' ') same = false; }
+    });
+    return same && words * (3 + 2 * ix.cfg.wmMaxLD1) <= INFX_MAX_WM_LISTS;
+}
 struct FusedIn { std::vector<infx_fused_query> fq; std::vector<infx_cov_query> cq; std::vector<infx_wm_list> lists; std::vector<int32_t> owned; };
 static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_results, int32_t enable_coverage, FusedIn& F) {
     Batch& B = *S->batch; const HostIndex& ix = e->ix; const int threads = e->threads; const uint32_t nq = B.nq;
@@ -634,6 +716,8 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
     fq.assign(nq, infx_fused_query{}); cq.assign(nq, infx_cov_query{});
     std::vector<std::vector<infx_wm_list>> qLists(nq); std::vector<std::vector<int32_t>> qOwned(nq);
     std::vector<int32_t> covErr(nq, 0);
+    const bool devWm = e->devLookups && ix.cfg.wordMatcher;
+    std::atomic<long long> nDev{0}, nHost{0};
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         WmResult wm;
         for (int64_t i = b; i < en; i++) {
@@ -647,15 +731,18 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
             if (isShort) { F.flags |= INFX_FQ_SHORT; int64_t pk = ix.prefixKeys.find(st); int shortCount = pk >= 0 ? (int)ix.prefixPop[pk] : 0; if (shortCount > 500) F.flags |= INFX_FQ_SHORTSKIP; }
             if (!covEnabled || (F.flags & INFX_FQ_SHORTSKIP)) continue;
             F.flags |= INFX_FQ_COV;
+            covErr[i] = prepare_cov_query(ix, st, cq[i]);
+            if (devWm && !covErr[i] && wm_on_device(ix, st)) { F.flags |= INFX_FQ_WMDEV; nDev++; continue; }      // k_wm resolves the words of cq[i] (lookup.hip.inc)
             auto pre = S->wmPre.find(st);            // computed by a peer rank (sharded planning): same index, same text, same descriptors
             if (pre != S->wmPre.end()) { qLists[i] = pre->second.lists; qOwned[i] = pre->second.owned; }
             else wm_descriptors(ix, st, wm, qLists[i], qOwned[i]);
-            covErr[i] = prepare_cov_query(ix, st, cq[i]);
+            nHost++;
         }
     });
     // a query outside the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length) is answered as "unsupported" (empty result,
     // flag bit 0) — it does not fail the other queries of the batch
     for (uint32_t i = 0; i < nq; i++) if (covErr[i]) { fq[i].flags = INFX_FQ_SKIP | INFX_FQ_UNSUPPORTED; qLists[i].clear(); qOwned[i].clear(); }
+    e->wmOnDevice += nDev.load(); e->wmOnHost += nHost.load();
     lists.clear(); owned.clear();
     for (uint32_t i = 0; i < nq; i++) {
         fq[i].wm_off = (uint32_t)lists.size(); fq[i].wm_count = (uint32_t)qLists[i].size();
@@ -679,7 +766,7 @@ static int32_t fused_inputs_for_phase3(infx_engine* e, infx_session* S, int32_t 
         infx_fused_query& q = F.fq[i];
         q.max_results = max_results;
         if (!(q.flags & INFX_FQ_SKIP)) q.dev = B.devOf.empty() ? -1 : B.devOf[i];
-        if (!cov) { q.flags &= ~INFX_FQ_COV; q.wm_count = 0; }
+        if (!cov) { q.flags &= ~(INFX_FQ_COV | INFX_FQ_WMDEV); q.wm_count = 0; }
     }
     out = B.pre;
     return INFX_OK;
@@ -1306,6 +1393,48 @@ int64_t infx_engine_wordmatcher(infx_engine* e, const uint16_t* q, int32_t len, 
     wm_collect(e->ix, t, true, wm);
     std::vector<int32_t> all;
     for (auto& l : wm.lists) all.insert(all.end(), l.p, l.p + l.n);
+    std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
+    for (size_t i = 0; i < all.size() && (int64_t)i < cap; i++) out[i] = all[i];
+    return (int64_t)all.size();
+}
+// ---- the planning lookups as the DEVICE answers them (parity tests: tests/test_gpu_lookups.py) ----
+int32_t infx_engine_device_lookups(infx_engine* e) { return !e ? -1 : (e->devLookups ? 1 : 0); }
+int32_t infx_engine_lookup_stats(infx_engine* e, int64_t* out4) {      // words expanded on the device / on the host, queries whose WordMatcher lists came from the device / the host
+    if (!e || !out4) return INFX_EINVAL;
+    out4[0] = e->ld1OnDevice.load(); out4[1] = e->ld1OnHost.load(); out4[2] = e->wmOnDevice.load(); out4[3] = e->wmOnHost.load();
+    return INFX_OK;
+}
+int32_t infx_engine_match_ld1_device(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int32_t cap) {      // like infx_engine_match_ld1; -1 / -2: the kernel handed the word back (status 1 / 2)
+    if (!e || len < 0 || (len && !q) || cap < 1 || !out) return -100;
+    if (!e->devLookups || !e->def || !e->def->stream) { g_eerr = "no device dictionaries"; return -100; }
+    uint32_t offs[2] = {0, (uint32_t)len}, count = 0, status = 0;
+    std::vector<int32_t> mem((size_t)cap);
+    int32_t rc = infx_ld1_expand(e->def->stream, 1, offs, q, (uint32_t)cap, mem.data(), &count, &status);
+    if (rc) { g_eerr = infx_last_error(); return -100 - rc; }
+    if (status) return -(int32_t)status;
+    for (uint32_t k = 0; k < count && k < (uint32_t)cap; k++) out[k] = mem[k];
+    return (int32_t)count;
+}
+int64_t infx_engine_wordmatcher_device(infx_engine* e, const uint16_t* q, int32_t len, int32_t* out, int64_t cap) {      // like infx_engine_wordmatcher, lists resolved by k_wm
+    if (!e || len < 0 || (len && !q)) return -1;
+    if (!e->devLookups || !e->ix.cfg.wordMatcher || !e->def || !e->def->stream) { g_eerr = "no device dictionaries"; return -1; }
+    const HostIndex& ix = e->ix;
+    ustr st((const u16*)q, (size_t)len);
+    if (!wm_on_device(ix, st)) { g_eerr = "query not admissible for the device lookup"; return -2; }
+    infx_cov_query cq; if (prepare_cov_query(ix, st, cq)) { g_eerr = "query exceeds the Stage-2 envelope"; return -2; }
+    size_t words = 0; for_each_word(st, [&](int, int l) { if (l >= 2) words++; });
+    std::vector<infx_wm_list> lists(INFX_MAX_WM_LISTS); std::vector<int32_t> owned(words * 4096 + 1); uint32_t nl = 0;
+    int32_t rc = infx_wm_lookup_debug(e->def->stream, &cq, lists.data(), &nl, owned.data(), (uint64_t)words * 4096);
+    if (rc) { g_eerr = infx_last_error(); return -1; }
+    std::vector<int32_t> all;
+    for (uint32_t l = 0; l < nl; l++) {
+        const infx_wm_list& L = lists[l];
+        const int32_t* p = L.src == 0 ? ix.wmExact.doc.data() : (L.src == 1 ? ix.wmLd1.doc.data() : owned.data());
+        const uint64_t lim = L.src == 0 ? ix.wmExact.doc.size() : (L.src == 1 ? ix.wmLd1.doc.size() : owned.size());
+        if (L.off + L.len > lim) { g_eerr = "device list out of range"; return -3; }
+        for (uint32_t i = 1; i < L.len; i++) if (p[L.off + i] <= p[L.off + i - 1]) { g_eerr = "device list not ascending"; return -4; }
+        all.insert(all.end(), p + L.off, p + L.off + L.len);
+    }
     std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
     for (size_t i = 0; i < all.size() && (int64_t)i < cap; i++) out[i] = all[i];
     return (int64_t)all.size();

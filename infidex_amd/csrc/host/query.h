@@ -236,6 +236,13 @@ struct FuzzyCache {
     }
     size_t size() { std::lock_guard<std::mutex> l(mu); return map.size(); }
 };
+// ExpandMissingTerm's filter over the LD1 matches (VectorModel.cs:660-683): members = matched terms that have postings
+inline std::shared_ptr<FuzzyUnion> union_of_matches(const HostIndex& ix, const int* m, size_t n) {
+    auto nf = std::make_shared<FuzzyUnion>();
+    for (size_t k = 0; k < n; k++) { const int id = m[k]; if (ix.df[id] > 0 && ix.terms.len((uint32_t)id)) nf->members.push_back(id); }
+    if (nf->members.empty()) nf->df.store(0);
+    return nf;
+}
 inline void materialise_union(const HostIndex& ix, FuzzyUnion& fz) {    // union of the (sorted) member lists: pairwise merges, smallest first
     std::vector<std::pair<const int32_t*, size_t>> lists;
     for (int id : fz.members) lists.push_back({ix.terms.doc.data() + ix.terms.off[id], (size_t)ix.terms.len((uint32_t)id)});
@@ -259,7 +266,7 @@ struct QueryPlan {
     std::vector<std::shared_ptr<FuzzyUnion>> fuzzy;  // per term (null for index terms)
     infx_query q{};
     bool noTerms = false;
-    struct Raw { int id; ustr text; std::shared_ptr<FuzzyUnion> fz; };
+    struct Raw { int id; ustr text; std::shared_ptr<FuzzyUnion> fz; bool pending = false; };      // pending: expansion deferred to the batch (device LD1 lookup)
     std::vector<Raw> rawTok;                          // between plan_tokens and plan_finish
     int depth = 0;
 };
@@ -275,7 +282,9 @@ inline void analyze_query(uview text, int minIndexSize, bool& canUse, bool& mixe
 
 // Pass 1: text preparation, term lookup, LD1 member lists of unknown words (df of new unions still pending).
 // hostUnions: build the unions on the host (engines without a device: planning introspection only).
-inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int depth, QueryPlan& P, bool hostUnions) {
+// deferLd1: an unknown word the expansion cache does not hold is only marked `pending`; the caller expands the distinct pending words of the whole
+// batch at once (ph_plan: on the device, infx_ld1_expand) and fills in `fz`.
+inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int depth, QueryPlan& P, bool hostUnions, bool deferLd1 = false) {
     P = QueryPlan(); P.depth = depth;
     size_t b = 0, e = raw.size();
     while (b < e && is_ws(raw[b])) b++;
@@ -310,6 +319,7 @@ inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
     for (auto& r : rawTok) {
         if (r.id >= 0 || r.text.size() < 4) continue;      // ExpandMissingTerm (VectorModel.cs:643-743): unknown words of length >= 4
         auto fz = fc.get(r.text);
+        if (!fz && deferLd1) { r.pending = true; continue; }
         if (!fz) {
             auto tF0 = std::chrono::steady_clock::now();
             std::vector<int> m; match_ld1(ix, r.text, m, 1024);

@@ -74,12 +74,21 @@ struct infx_index {
     std::vector<uint64_t> hPsOff;
     int rank = 0, nranks = 1;
     ncclComm_t comm = nullptr;         // infx_set_shard_comm
+    struct DevLookup* lk = nullptr;    // dictionaries / term trie of the device-side planning lookups (lookup.hip.inc); owned, freed by infx_destroy
+    bool haveDict = false, haveTrie = false;
 };
 
 template <class Tp> static hipError_t dalloc(infx_index* ix, Tp** p, size_t n) {
     void* v = nullptr; hipError_t e = hipMalloc(&v, std::max<size_t>(n, 1) * sizeof(Tp));
     if (e == hipSuccess) { ix->allocs.push_back(v); *p = (Tp*)v; }
     return e;
+}
+
+template <class Tp> static int32_t dcopy(infx_index* ix, const Tp** out, const Tp* src, size_t n) {
+    Tp* d = nullptr;
+    HIPCHK(dalloc(ix, &d, n));
+    if (n) HIPCHK(hipMemcpy(d, src, n * sizeof(Tp), hipMemcpyHostToDevice));
+    *out = d; return INFX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -163,11 +172,16 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 }
 
 #include "stage1.hip.inc"
+// The measured-slower alternative designs of k_accumulate (k_accumulate2/3/4: bit-identical, 10.7 / 7.64 / 8.08 ms against 7.2 ms) are
+// experiments, not product: they are compiled only into the library tests/test_gpu_parity.py::test_accumulate_designs_agree_bit_for_bit builds
+// (-DINFX_BUILD_EXPERIMENTS, infidex_amd/build.py build_experiments) and selected there with INFX_ACC_V2 / _V3 / _V4.
+#ifdef INFX_BUILD_EXPERIMENTS
 #include "stage1b.hip.inc"
 #define ACC_V3_DEFAULT 0
 #include "stage1c.hip.inc"
 #define ACC_V4_DEFAULT 0
 #include "stage1d.hip.inc"
+#endif
 #include "exact1.hip.inc"
 #include "exact3.hip.inc"
 #include "exactsh.hip.inc"
@@ -218,6 +232,7 @@ __host__ __device__ static inline SelRule make_rule(const infx_query& Q, const u
 }
 
 #include "fused.hip.inc"
+#include "lookup.hip.inc"
 #include "filter.hip.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -284,6 +299,7 @@ struct infx_stream {
     void* scratch[16] = {}; size_t capScratch[16] = {};      // infx_stream_scratch
     void *dHugeWs = nullptr, *dHugeCnt = nullptr; size_t capHugeWs = 0, capHugeCnt = 0;      // k_stage2's global-workspace pass
     ncclComm_t comm = nullptr;                                 // infx_stream_comm: this stream's own communicator (several batches in flight per rank)
+    void *dLWordOff = nullptr, *dLChars = nullptr, *dLMembers = nullptr, *dLCount = nullptr; size_t capLWordOff = 0, capLChars = 0, capLMembers = 0, capLCount = 0;   // infx_ld1_expand
 };
 
 #define S2_HUGE_POOL_U16 (32u << 20)      // token-table pool of k_stage2's over-long-document pass: 64 MB per stream (a 700-word row takes 5.7 KB, a 32 768-token one 265 KB)
@@ -420,6 +436,7 @@ template <int R> static bool acc_lds_layout_ok() {
     }();
     return ok;
 }
+#ifdef INFX_BUILD_EXPERIMENTS
 template <int R, int MW, int CAP> static bool acc2_launch(infx_stream* s, uint32_t nq, Arena ar, int useGrp) {
     static const bool ok = [] { hipFuncAttributes a{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate2<R, MW, CAP>) == hipSuccess && a.sharedSizeBytes == 0; }();
     if (!ok) return false;                                   // LDS8 / LDS32 address the dynamic block from LDS address 0: no static __shared__ allowed
@@ -469,7 +486,9 @@ template <int R, int MW, int SUP> static bool acc4_launch(infx_stream* s, uint32
 template <int R, int SUP> static bool acc4_fits(const infx_index* ix) {
     return (size_t)R * SUP <= 32768 && (65536 % ((size_t)R * SUP)) == 0 && (!ix->d.packed || (uint64_t)ix->d.N + (uint64_t)R * SUP + 512 < (1ull << 24));
 }
+#endif
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp, int maxRef) {
+#ifdef INFX_BUILD_EXPERIMENTS
     if (acc_v4_enabled() && acc_v1_forced() && !acc_v3_enabled()) {
         const int mw = ar.maskWords == 2 ? 2 : 1;
         bool done = false, ok = true;
@@ -488,6 +507,9 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
         if (!ok) s->accLayoutBad = true;
         return;
     }
+#else
+    (void)maxRef;
+#endif
     if (!acc_lds_layout_ok<R>()) { s->accLayoutBad = true; return; }
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
     const int stripe = acc_stripe();
@@ -618,6 +640,7 @@ void infx_destroy(infx_index* ix) {
     hipSetDevice(ix->cfg.device);
     if (ix->comm && rccl_api().ok) rccl_api().destroy(ix->comm);
     for (void* p : ix->allocs) hipFree(p);
+    delete ix->lk;
     delete ix;
 }
 
@@ -866,7 +889,7 @@ void infx_stream_destroy(infx_stream* s) {
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
                   s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters,
-                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt};
+                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
     if (s->comm && rccl_api().ok) rccl_api().destroy(s->comm);
@@ -1145,9 +1168,117 @@ int32_t infx_upload_wordmatcher(infx_index* ix, uint64_t n_exact, const int32_t*
 }
 
 
+// ---- dictionaries of the device-side planning lookups (lookup.hip.inc) --------------------------------------------------------------
+static int32_t dict_upload(infx_index* ix, DevDict& D, uint32_t nkeys, const uint32_t* key_offs, const uint16_t* chars, const uint64_t* list_offs, uint64_t ndocs) {
+    D = DevDict{};
+    if (nkeys == 0) return INFX_OK;
+    for (uint32_t i = 0; i < nkeys; i++) if (key_offs[i + 1] < key_offs[i] || list_offs[i + 1] < list_offs[i]) return fail(INFX_EINVAL, "dictionary offsets must ascend%s");
+    if (list_offs[nkeys] > ndocs) return fail(INFX_EINVAL, "dictionary list offsets exceed the uploaded doc-id array%s");
+    { int32_t rc_ = dcopy(ix, &D.keyOff, key_offs, (size_t)nkeys + 1); if (rc_) return rc_; }
+    { int32_t rc_ = dcopy(ix, &D.chars, chars, (size_t)key_offs[nkeys]); if (rc_) return rc_; }
+    { int32_t rc_ = dcopy(ix, &D.listOff, list_offs, (size_t)nkeys + 1); if (rc_) return rc_; }
+    uint64_t cap = 1024; while (cap < (uint64_t)nkeys * 2) cap <<= 1;
+    if (cap > 0x80000000ull) return fail(INFX_ECAPACITY, "dictionary too large%s");
+    unsigned long long* slots = nullptr;
+    HIPCHK(dalloc(ix, &slots, (size_t)cap));
+    HIPCHK(hipMemset(slots, 0, (size_t)cap * 8));
+    k_dict_build<<<(nkeys + 255) / 256, 256>>>(slots, (uint32_t)(cap - 1), D.keyOff, D.chars, nkeys);
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+    D.slots = slots; D.mask = (uint32_t)(cap - 1);
+    return INFX_OK;
+}
+int32_t infx_upload_wm_dictionary(infx_index* ix, uint32_t n_exact, const uint32_t* exact_key_offs, const uint16_t* exact_chars, const uint64_t* exact_list_offs,
+                                  uint32_t n_ld1, const uint32_t* ld1_key_offs, const uint16_t* ld1_chars, const uint64_t* ld1_list_offs,
+                                  uint32_t n_words, const uint32_t* word_offs, const uint16_t* word_chars, const int32_t* word_last_doc,
+                                  uint32_t n_affix, const uint32_t* affix_fwd, const uint32_t* affix_rev, int32_t min_ld1, int32_t max_ld1) {
+    if (!ix || (n_exact && (!exact_key_offs || !exact_chars || !exact_list_offs)) || (n_ld1 && (!ld1_key_offs || !ld1_chars || !ld1_list_offs)) ||
+        (n_words && (!word_offs || !word_chars || !word_last_doc)) || (n_affix && (!affix_fwd || !affix_rev))) return fail(INFX_EINVAL, "null argument%s");
+    if (!ix->haveWm) return fail(INFX_EINVAL, "infx_upload_wordmatcher comes first%s");
+    if (ix->haveDict) return fail(INFX_EINVAL, "WordMatcher dictionary already uploaded%s");
+    if (min_ld1 < 1 || max_ld1 < min_ld1 || 3 + 2 * max_ld1 > INFX_MAX_WM_LISTS) return fail(INFX_EINVAL, "bad LD1 word-length window%s");
+    for (uint32_t i = 0; i < n_affix; i++) if (affix_fwd[i] >= n_words || affix_rev[i] >= n_words) return fail(INFX_EINVAL, "affix word id out of range%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    if (!ix->lk) ix->lk = new DevLookup{};
+    DevLookup& K = *ix->lk;
+    { int32_t rc_ = dict_upload(ix, K.exact, n_exact, exact_key_offs, exact_chars, exact_list_offs, ix->nWmExact); if (rc_) return rc_; }
+    { int32_t rc_ = dict_upload(ix, K.ld1, n_ld1, ld1_key_offs, ld1_chars, ld1_list_offs, ix->nWmLd1); if (rc_) return rc_; }
+    if (n_words) {
+        { int32_t rc_ = dcopy(ix, &K.wordOff, word_offs, (size_t)n_words + 1); if (rc_) return rc_; }
+        { int32_t rc_ = dcopy(ix, &K.wordChars, word_chars, (size_t)word_offs[n_words]); if (rc_) return rc_; }
+        { int32_t rc_ = dcopy(ix, &K.wordLastDoc, word_last_doc, (size_t)n_words); if (rc_) return rc_; }
+    }
+    if (n_affix) {
+        { int32_t rc_ = dcopy(ix, &K.affixFwd, affix_fwd, (size_t)n_affix); if (rc_) return rc_; }
+        { int32_t rc_ = dcopy(ix, &K.affixRev, affix_rev, (size_t)n_affix); if (rc_) return rc_; }
+    }
+    K.nAffix = n_affix; K.minLd1 = min_ld1; K.maxLd1 = max_ld1;
+    ix->haveDict = true;
+    return INFX_OK;
+}
+int32_t infx_upload_term_trie(infx_index* ix, uint32_t n_nodes, const uint32_t* edge_start, const uint16_t* edge_label, const uint32_t* edge_child, const int32_t* node_term,
+                              uint32_t n_terms, const uint32_t* sorted_terms) {
+    if (!ix || !n_nodes || !edge_start || !node_term || (n_terms && !sorted_terms)) return fail(INFX_EINVAL, "null argument%s");
+    if (ix->haveTrie) return fail(INFX_EINVAL, "term trie already uploaded%s");
+    const uint32_t ne = edge_start[n_nodes];
+    if (ne && (!edge_label || !edge_child)) return fail(INFX_EINVAL, "null argument%s");
+    for (uint32_t v = 0; v < n_nodes; v++) { if (edge_start[v + 1] < edge_start[v]) return fail(INFX_EINVAL, "edge offsets must ascend%s"); if (node_term[v] >= (int32_t)n_terms) return fail(INFX_EINVAL, "node term id out of range%s"); }
+    for (uint32_t k = 0; k < ne; k++) if (edge_child[k] >= n_nodes) return fail(INFX_EINVAL, "edge child out of range%s");
+    std::vector<uint32_t> rank(n_terms, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < n_terms; i++) { if (sorted_terms[i] >= n_terms || rank[sorted_terms[i]] != 0xFFFFFFFFu) return fail(INFX_EINVAL, "sorted_terms is not a permutation%s"); rank[sorted_terms[i]] = i; }
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    if (!ix->lk) ix->lk = new DevLookup{};
+    DevLookup& K = *ix->lk;
+    { int32_t rc_ = dcopy(ix, &K.rEdgeStart, edge_start, (size_t)n_nodes + 1); if (rc_) return rc_; }
+    { int32_t rc_ = dcopy(ix, &K.rEdgeLabel, edge_label, (size_t)ne); if (rc_) return rc_; }
+    { int32_t rc_ = dcopy(ix, &K.rEdgeChild, edge_child, (size_t)ne); if (rc_) return rc_; }
+    { int32_t rc_ = dcopy(ix, &K.rTerm, node_term, (size_t)n_nodes); if (rc_) return rc_; }
+    { int32_t rc_ = dcopy(ix, &K.termRank, (const uint32_t*)rank.data(), (size_t)n_terms); if (rc_) return rc_; }
+    { int32_t rc_ = dcopy(ix, &K.sortedTerms, sorted_terms, (size_t)n_terms); if (rc_) return rc_; }
+    K.nTerms = n_terms; K.nNodes = n_nodes;
+    ix->haveTrie = true;
+    return INFX_OK;
+}
+int32_t infx_ld1_expand(infx_stream* s, uint32_t nwords, const uint32_t* word_offs, const uint16_t* chars, uint32_t cap, int32_t* members_out, uint32_t* counts_out, uint32_t* status_out) {
+    if (!s || (nwords && (!word_offs || !members_out || !counts_out || !status_out || (word_offs[nwords] && !chars))) || cap == 0) return fail(INFX_EINVAL, "null argument%s");
+    if (nwords == 0) return INFX_OK;
+    infx_index* ix = s->ix;
+    if (!ix->haveTrie) return fail(INFX_EINVAL, "infx_upload_term_trie has not been called%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    const size_t nch = word_offs[nwords];
+    GROW(s->dLWordOff, s->capLWordOff, ((size_t)nwords + 1) * 4);
+    GROW(s->dLChars, s->capLChars, std::max<size_t>(1, nch) * 2);
+    GROW(s->dLMembers, s->capLMembers, (size_t)nwords * cap * 4);
+    GROW(s->dLCount, s->capLCount, (size_t)nwords * 8);
+    UP(s->dLWordOff, word_offs, ((size_t)nwords + 1) * 4);
+    UP(s->dLChars, chars, nch * 2);
+    uint32_t* dCnt = (uint32_t*)s->dLCount; uint32_t* dSt = dCnt + nwords;
+    k_ld1<<<nwords, WAVE, 0, s->st>>>(*ix->lk, (const uint32_t*)s->dLWordOff, (const uint16_t*)s->dLChars, nwords, cap, (int32_t*)s->dLMembers, dCnt, dSt);
+    HIPCHK(hipGetLastError());
+    DOWN(counts_out, dCnt, (size_t)nwords * 4);
+    DOWN(status_out, dSt, (size_t)nwords * 4);
+    SYNC();
+    // only the members that exist travel back: one copy per word of min(count, cap) ids (a few hundred bytes each) would be many small DMAs, so
+    // the rows are fetched in one strided pass up to the largest count of the batch
+    uint32_t mx = 0; for (uint32_t i = 0; i < nwords; i++) if (!status_out[i]) mx = std::max(mx, std::min(counts_out[i], cap));
+    if (mx) {
+        std::vector<int32_t> tmp((size_t)nwords * mx);
+        void* p = pin_take(s, tmp.size() * 4); if (!p) return fail(INFX_ENOMEM, "hipHostMalloc staging failed%s");
+        HIPCHK(hipMemcpy2DAsync(p, (size_t)mx * 4, s->dLMembers, (size_t)cap * 4, (size_t)mx * 4, nwords, hipMemcpyDeviceToHost, s->st)); s->unsynced = true;
+        SYNC();
+        for (uint32_t i = 0; i < nwords; i++) { const uint32_t c = status_out[i] ? 0u : std::min(counts_out[i], cap); std::memcpy(members_out + (size_t)i * cap, (const int32_t*)p + (size_t)i * mx, (size_t)c * 4); }
+    }
+    return INFX_OK;
+}
+
 static uint32_t pow2_at_least(uint32_t v, uint32_t lo) { uint32_t p = lo; while (p < v) p <<= 1; return p; }
 
 // ---- fused pipeline pieces (shared by infx_search_fused and the sharded stage API) ------------------------------------------
+static uint32_t wm_words(const infx_cov_query& c) {      // words k_wm looks up: fusion tokens of at least two characters (WordMatcherLookup.cs:27-31)
+    uint32_t n = 0; const int nt = std::min(c.num_fusion_tokens, 2 * INFX_MAX_QUERY_TOKENS);
+    for (int t = 0; t < nt; t++) if (c.ftok_len[t] >= 2 && (int)c.ftok_off[t] + (int)c.ftok_len[t] <= c.text_len) n++;
+    return n;
+}
 static int32_t fused_check_queries(infx_index* ix, uint32_t nd, uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq,
                                    uint32_t nlists, const infx_wm_list* lists, uint32_t owned_n, int32_t depth, int32_t max_results) {
     if (nd > nq || max_results < 1 || depth < 1 || depth > ix->cfg.max_depth) return fail(INFX_EINVAL, "bad batch shape%s");
@@ -1156,6 +1287,12 @@ static int32_t fused_check_queries(infx_index* ix, uint32_t nd, uint32_t nq, con
         if (fq[i].dev >= (int32_t)nd) return fail(INFX_EINVAL, "fused query refers to a missing Stage-1 query%s");
         if (fq[i].wm_count > INFX_MAX_WM_LISTS || (uint64_t)fq[i].wm_off + fq[i].wm_count > nlists) return fail(INFX_ECAPACITY, "too many WordMatcher lists for one query%s");
         if (fq[i].wm_count) anyWm = true;
+        if (fq[i].flags & INFX_FQ_WMDEV) {
+            if (!ix->haveDict) return fail(INFX_EINVAL, "INFX_FQ_WMDEV needs infx_upload_wm_dictionary%s");
+            if (fq[i].wm_count) return fail(INFX_EINVAL, "a query takes its WordMatcher lists either from the caller or from the device lookup%s");
+            if ((fq[i].flags & INFX_FQ_COV) && !(fq[i].flags & INFX_FQ_SKIP) && wm_words(cq[i]) * (uint32_t)(3 + 2 * ix->lk->maxLd1) > INFX_MAX_WM_LISTS)
+                return fail(INFX_ECAPACITY, "too many words for the device WordMatcher lookup (hand the lists over instead)%s");
+        }
         if ((fq[i].flags & INFX_FQ_COV) && !(fq[i].flags & INFX_FQ_SKIP) &&
             (cq[i].num_tokens > INFX_MAX_QUERY_TOKENS || cq[i].text_len > INFX_MAX_QUERY_CHARS || cq[i].num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS))
             return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope%s");
@@ -1214,12 +1351,30 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
     GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
     GROW(s->dFPairs, s->capFPairs, (size_t)ncand * 4);
     if (want_debug) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
-    UP(s->dFQ, fq, (size_t)nq * sizeof(infx_fused_query));
+    // queries flagged INFX_FQ_WMDEV get their WordMatcher lists from k_wm: a block of INFX_MAX_WM_LISTS descriptors per query behind the caller's lists,
+    // one WM_AFFIX_CAP region of `owned` per looked-up word behind the caller's ids (the regions are assigned here: `reserved` = first word slot)
+    std::vector<infx_fused_query> fqDev; uint64_t wmSlots = 0;
+    for (uint32_t i = 0; i < nq; i++) if (fq[i].flags & INFX_FQ_WMDEV) {
+        if (fqDev.empty()) fqDev.assign(fq, fq + nq);
+        fqDev[i].reserved = (int32_t)wmSlots;
+        if ((fq[i].flags & INFX_FQ_COV) && !(fq[i].flags & INFX_FQ_SKIP)) wmSlots += wm_words(cq[i]);
+    }
+    const bool wmDev = !fqDev.empty();
+    if (wmDev) {
+        if (wmSlots * WM_AFFIX_CAP + owned_n > 0x7FFFFFF0ull) return fail(INFX_ECAPACITY, "device WordMatcher lookup: too many query words in one batch%s");
+        GROW(s->dFLists, s->capFLists, ((size_t)nlists + (size_t)nq * INFX_MAX_WM_LISTS) * sizeof(infx_wm_list));
+        GROW(s->dFOwned, s->capFOwned, ((size_t)owned_n + (size_t)wmSlots * WM_AFFIX_CAP + 1) * 4);
+    }
+    UP(s->dFQ, wmDev ? fqDev.data() : fq, (size_t)nq * sizeof(infx_fused_query));
     UP(s->dFLists, lists, (size_t)nlists * sizeof(infx_wm_list));
     UP(s->dFOwned, owned, (size_t)owned_n * 4);
     UP(s->dCovQ, cq, (size_t)nq * sizeof(infx_cov_query));
     HIPCHK(hipMemsetAsync(s->dCovO, 0, (size_t)ncand * sizeof(infx_cov_out), s->st));
     HIPCHK(hipEventRecord(s->evP0, s->st));
+    if (wmDev) {
+        k_wm<<<nq, WAVE, 0, s->st>>>(*ix->lk, (infx_fused_query*)s->dFQ, (const infx_cov_query*)s->dCovQ, nq, (infx_wm_list*)s->dFLists, nlists, (int32_t*)s->dFOwned, (uint64_t)owned_n);
+        HIPCHK(hipGetLastError());
+    }
     {
         const size_t Pp = std::max<size_t>(Dp, P2_CAP);
         const size_t lds = (size_t)Dp * 4 * 4 + Pp * 4 + (size_t)P2_CAP * 4 + (size_t)Dp * 8 + (size_t)Dp * 2 + Pp + (size_t)P2_MAXLISTS * (8 + 4 + 4 + 4) + (P2_THREADS + 2) * 4 + (size_t)Dall * 8 + 64;
@@ -1309,6 +1464,33 @@ static void fused_scatter_results(uint32_t nq, int32_t max_results, const FusedR
 static void fused_take_metas(infx_stream* s, const std::vector<FusedMeta>& metas) {
     s->fusedS1 = s->fusedCands = s->fusedTextBytes = 0;
     for (auto& m : metas) { s->fusedS1 += m.s1Count; s->fusedCands += m.candCount; s->fusedTextBytes += (uint64_t)m.pad0 + ((uint64_t)m.pad1 << 32); }
+}
+
+int32_t infx_wm_lookup_debug(infx_stream* s, const infx_cov_query* cq, infx_wm_list* lists_out, uint32_t* nlists_out, int32_t* owned_out, uint64_t owned_cap) {
+    if (!s || !cq || !lists_out || !nlists_out || (owned_cap && !owned_out)) return fail(INFX_EINVAL, "null argument%s");
+    infx_index* ix = s->ix;
+    if (!ix->haveDict) return fail(INFX_EINVAL, "infx_upload_wm_dictionary has not been called%s");
+    const uint32_t words = wm_words(*cq);
+    if (cq->text_len > INFX_MAX_QUERY_CHARS || cq->num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS) return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope%s");
+    if (words * (uint32_t)(3 + 2 * ix->lk->maxLd1) > INFX_MAX_WM_LISTS) return fail(INFX_ECAPACITY, "too many words for the device WordMatcher lookup%s");
+    if ((uint64_t)words * WM_AFFIX_CAP > owned_cap) return fail(INFX_EINVAL, "owned_out too small%s");
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    infx_fused_query fq{}; fq.dev = -1; fq.flags = INFX_FQ_COV | INFX_FQ_WMDEV; fq.max_results = 1; fq.reserved = 0;
+    GROW(s->dFQ, s->capFQ, sizeof(infx_fused_query));
+    GROW(s->dFLists, s->capFLists, (size_t)INFX_MAX_WM_LISTS * sizeof(infx_wm_list));
+    GROW(s->dFOwned, s->capFOwned, ((size_t)words * WM_AFFIX_CAP + 1) * 4);
+    GROW(s->dCovQ, s->capCovQ, sizeof(infx_cov_query));
+    UP(s->dFQ, &fq, sizeof fq); UP(s->dCovQ, cq, sizeof *cq);
+    k_wm<<<1, WAVE, 0, s->st>>>(*ix->lk, (infx_fused_query*)s->dFQ, (const infx_cov_query*)s->dCovQ, 1, (infx_wm_list*)s->dFLists, 0, (int32_t*)s->dFOwned, 0ull);
+    HIPCHK(hipGetLastError());
+    infx_fused_query back{};
+    DOWN(&back, s->dFQ, sizeof back);
+    DOWN(lists_out, s->dFLists, (size_t)INFX_MAX_WM_LISTS * sizeof(infx_wm_list));
+    if (words) DOWN(owned_out, s->dFOwned, (size_t)words * WM_AFFIX_CAP * 4);
+    SYNC();
+    *nlists_out = back.wm_count;
+    return INFX_OK;
 }
 
 int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint32_t nterms, const infx_term* terms,

@@ -84,9 +84,10 @@ def load_library():
     """Loads the in-tree HIP extension; raises (never falls back) when it is missing."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise InfidexError(3, f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
-        L = C.CDLL(LIB_PATH)
+        path = os.environ.get("INFX_LIB") or LIB_PATH       # INFX_LIB: the experiments build of the same library (A/B test of the k_accumulate designs)
+        if not os.path.exists(path):
+            raise InfidexError(3, f"{path} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(path)
         L.infx_engine_last_error.restype = C.c_char_p
         L.infx_last_error.restype = C.c_char_p
         L.infx_engine_wordmatcher.restype = C.c_int64
@@ -356,6 +357,34 @@ class SearchEngine:
     def wordmatcher(self, text, cap=1 << 22):
         a = _u16(text); out = np.zeros(cap, np.int32)
         n = self.L.infx_engine_wordmatcher(self.h, _p(a, C.c_uint16), len(a), _p(out, C.c_int32), C.c_int64(cap))
+        return out[:min(n, cap)].copy()
+
+    # ---- the planning lookups as the device answers them (infidex_engine.h; tests/test_gpu_lookups.py) ----
+    def device_lookups(self) -> bool:
+        return self.L.infx_engine_device_lookups(self.h) == 1
+
+    def lookup_stats(self):
+        out = np.zeros(4, np.int64)
+        self._check(self.L.infx_engine_lookup_stats(self.h, _p(out, C.c_int64)))
+        return dict(ld1_device=int(out[0]), ld1_host=int(out[1]), wm_device=int(out[2]), wm_host=int(out[3]))
+
+    def match_ld1_device(self, q, cap=1024):
+        """(count, first `cap` term ids) like match_ld1; count -1 / -2: the kernel handed the word back to the host walk."""
+        a = _u16(q); out = np.zeros(cap, np.int32)
+        c = self.L.infx_engine_match_ld1_device(self.h, _p(a, C.c_uint16), len(a), _p(out, C.c_int32), cap)
+        if c <= -100:
+            self._check(-100 - c if c < -100 else 1)
+        return c, out[:max(0, min(c, cap))].copy()
+
+    def wordmatcher_device(self, text, cap=1 << 22):
+        """Ascending unique doc ids of the lists k_wm emits for the (already prepared) search text; None: not admissible for the device lookup."""
+        a = _u16(text); out = np.zeros(cap, np.int32)
+        self.L.infx_engine_wordmatcher_device.restype = C.c_int64
+        n = self.L.infx_engine_wordmatcher_device(self.h, _p(a, C.c_uint16), len(a), _p(out, C.c_int32), C.c_int64(cap))
+        if n == -2:
+            return None
+        if n < 0:
+            self._check(1)
         return out[:min(n, cap)].copy()
 
     def prefix_pop(self, p):

@@ -422,7 +422,8 @@ class ShardedSearcher:
         import os
         self.native = (os.environ.get("INFX_SHARD_NATIVE", "1") != "0") if native is None else bool(native)
         self.comm = comm
-        self.partition_planning = partition_planning and comm.world > 1
+        # with the dictionaries on the device (the default) the expensive lookups are kernels on every rank's own GPU: nothing is left to partition
+        self.partition_planning = partition_planning and comm.world > 1 and not engine.device_lookups()
         K = max(1, int(sessions)) if self.native else 1
         self.sessions = [ShardSession(engine) for _ in range(K)]
         self.sess = self.sessions[0]

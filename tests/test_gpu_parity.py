@@ -434,6 +434,8 @@ for tag in ("plain", "deleted"):
 np.savez(sys.argv[1], **out)
 '''
     res = []
+    from infidex_amd import build as _build
+    exp_lib = _build.build_experiments()
     variants = [dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate
                 dict(INFX_ACC_V2="1", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate2
                 dict(INFX_ACC_V2="0", INFX_ACC_V3="1", INFX_ACC_V4="0"),                      # k_accumulate3
@@ -441,6 +443,7 @@ np.savez(sys.argv[1], **out)
                 dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="1", INFX_ACC_SUP="4")]    # ... of 4 ranges
     for vi, var in enumerate(variants):
         env = dict(os.environ); env.update(var)
+        env["INFX_LIB"] = exp_lib                     # the alternative designs are not part of the product library (-DINFX_BUILD_EXPERIMENTS)
         env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         out = str(tmp_path / f"acc{vi}.npz")
         subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=900)
