@@ -30,6 +30,49 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+PMC_FILE = "r04_pmc.json"
+
+
+def kernel_sha16():
+    """sha256 (16 hex digits) of what decides k_accumulate's traffic: the kernel source and its launch code (grid, XCD-aware block map, LDS size)."""
+    import hashlib
+    csrc = os.path.join(ROOT, "infidex_amd", "csrc")
+    h = hashlib.sha256(open(os.path.join(csrc, "stage1.hip.inc"), "rb").read())
+    src = open(os.path.join(csrc, "infidex_hip.hip")).read()
+    a = src.index("template <int R> static void launch_acc("); b = src.index("// k_exact1 behind k_select", a)
+    h.update(src[a:b].encode())
+    return h.hexdigest()[:16]
+
+
+def roofline_by_kernel(roof):
+    """Every kernel that takes >= 5 % of the GPU time of a batch, priced like k_accumulate: algorithmic bytes of the launch (DESIGN.md section 4 defines them per
+    kernel) / duration (HIP events on the launch stream, one batch in flight) against the HBM peak, with what actually bounds it."""
+    def m(key):
+        vals = [t[key] for t in roof if key in t]
+        return float(np.mean(vals)) if vals else 0.0
+    rows = m("stage1_candidates"); s2rows = m("stage2_candidates"); s2bytes = m("stage2_text_bytes"); repl = m("exact_replays")
+    nq = m("queries") or 1000.0
+    spec = [
+        # kernel, duration key, algorithmic bytes, bound, what the bytes are
+        ("k_select", "k_select_ms", rows * 9.0, "latency", "arena rows x (class 1 B + score 4 B + doc id 4 B), each read once (the radix select reads class + score once per pass: 2-3 passes)"),
+        ("k_ex_scan", "k_ex_scan_ms", m("replay_rows") * 12.0, "serial-latency", "rows of the flagged queries x (class 1 B + score 4 B + directory / candidate-list 7 B): one workgroup per query walks them in doc order"),
+        ("k_ex_chunk", "k_ex_chunk_ms", m("replay_rows") * (4.0 + 8.0 + 4.0 + 4.0), "issue", "candidate rows of the flagged queries x (list entry 4 B + hit mask 8 B + tf exceptions 4 B + doc length 4 B)"),
+        ("k_ex_heap", "k_ex_heap_ms", m("replay_rows") * 8.0, "serial-latency", "emitted candidates x (doc 4 B + score 4 B); time = ~3-4 k dependent 4-ary heap operations per query on one wave"),
+        ("k_prep2", "k_prep2_ms", nq * 500 * 8.0 + s2rows * 16.0, "latency", "Stage-1 rows in (8 B) + candidate rows out (16 B) + WordMatcher list probes (binary searches)"),
+        ("k_stage2", "k_stage2_ms", s2bytes + s2rows * (16.0 + 12.0), "issue", "UTF-16 text of every scored row + candidate row in (16 B) + result out (12 B); integer string code, one lane per row"),
+    ]
+    out = []
+    tot = sum(m(k) for k in ("k_accumulate_ms", "k_select_ms", "k_replay_ms", "k_prep2_ms", "k_stage2_ms", "k_finalize_ms")) or 1.0
+    for name, key, bytes_, bound, what in spec:
+        ms = m(key)
+        if ms <= 0:
+            continue
+        ach = bytes_ / (ms * 1e-3) / 1e9
+        out.append({"kernel": name, "avg_launch_ms": ms, "share_of_gpu_time": ms / tot, "algorithmic_bytes_per_launch": bytes_, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "bound": bound, "bytes_are": what})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,7 +260,7 @@ def main():
                     ts = time.time()
                     keys, scores, ties, counts, flags = sess.search_packed(batches[s][0], batches[s][1], k, 500)
                     lat[s] = (time.time() - ts) * 1000.0
-                    tim[s] = sess.last_timings()
+                    tim[s] = sess.last_timings(kernels=(s % 4 == 0))      # kernel durations on every fourth batch: resolving them is HIP API traffic
                     results[s] = (keys, counts)
             except Exception as ex:  # noqa: BLE001
                 errors.append(ex)
@@ -264,9 +307,15 @@ def main():
         single_ms = float(np.median(ls[8:]))
     STAGE_KEYS = ("plan_ms", "stage1_ms", "prep2_ms", "stage2_ms", "post_ms", "k_accumulate_ms", "k_select_ms", "k_replay_ms", "k_prep2_ms", "k_stage2_ms", "k_finalize_ms")
     for t in list(tim) + list(roof):                   # the library times rules + select + replay as one span: report select and replay apart
-        if "k_select_only" not in t:
+        if "k_select_only" not in t and "k_select_ms" in t:
             t["k_select_only"] = True; t["k_select_ms"] = max(0.0, t["k_select_ms"] - t.get("k_replay_ms", 0.0))
-    stage_me = {kk: float(np.mean([t[kk] for t in tim])) for kk in STAGE_KEYS}
+        t.setdefault("queries", args.batch)
+        if "exact_replays" in t and "stage1_candidates" in t:      # candidate rows of the queries the replay handles, estimated from the flagged share
+            t.setdefault("replay_rows", t["stage1_candidates"] * t["exact_replays"] / max(1, args.batch))
+    stage_me = {kk: float(np.mean([t[kk] for t in tim if kk in t])) for kk in STAGE_KEYS if any(kk in t for t in tim)}
+    for kk in ("plan_tokens_ms", "plan_ld1_device_ms", "plan_union_device_ms", "plan_finish_ms"):      # where plan_ms went (fused sessions)
+        if tim and all(kk in t for t in tim):
+            stage_me[kk] = float(np.mean([t[kk] for t in tim]))
     stage_ranks = None
     if dist is not None and world > 1:          # per-phase milliseconds of EVERY rank (host phases are replicated, device phases shrink with W)
         stage_ranks = [None] * world
@@ -275,14 +324,16 @@ def main():
     alg = float(np.mean([t["alg_bytes"] for t in roof]))
     streamed = float(np.mean([t["streamed_bytes"] for t in roof]))
     achieved = alg / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    qw = str(syn.cfg["qwords"][0]) if syn.cfg["qwords"][0] == syn.cfg["qwords"][1] else f"{syn.cfg['qwords'][0]}-{syn.cfg['qwords'][1]}"
+    lk = eng.lookup_stats() if hasattr(eng, "lookup_stats") else None
     out = {
         "metric": ("queries/sec, 10M-doc corpus, top-k=20 (whole hot path, index resident in HBM)" if args.config == 4 and args.docs == full else
                    f"queries/sec, config {args.config}, {args.docs} docs, top-k={k} (whole hot path, index resident in HBM)"),
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1000.0, "higher_is_better": True, "scaling": ("strong" if sharded else "weak"),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE config {args.config}: {syn.cfg['docs']} docs, vocab {syn.cfg['vocab']}, {args.batch}-query batches, "
-                               f"2-3 word queries {int(syn.cfg['fuzz'] * 100)}% fuzzed, depth 500, top-{k}",
+        "config": {"workload": f"BASELINE config {args.config}: {syn.cfg['docs']} docs, vocab {syn.cfg['vocab']}, {len(syn.cfg['fields'])} field(s), {args.batch}-query batches, "
+                               f"{qw}-word queries {int(syn.cfg['fuzz'] * 100)}% fuzzed, depth 500, top-{k}" + (f", filter {flt!r} + facets" if flt else ""),
                    "docs": syn.cfg["docs"], "batch": args.batch, "top_k": k, "coverage_depth": 500,
                    "sessions_in_flight": nsess,
                    "parallelism": "single GPU" if world == 1 else (f"{world} document shards, count all-reduce + RCCL all-gather of per-shard top-500 + owner-scored Stage 2" if sharded
@@ -293,7 +344,9 @@ def main():
         # Stage-1 host part (phase API only), Stage-2 preparation (fused pipeline: WordMatcher descriptors + PrepareQuery),
         # the wait for the device (fused: the whole device pipeline behind one synchronisation), host post-processing
         "stage_ms_per_step": stage_me,
-        "roofline": {"kernel": "k_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # "bound": what limits the kernel by the counters of profiles/ (instruction issue), NOT what it is priced against: `peak` stays the HBM roofline the
+        # path is bounded by in principle (byte streaming, no MFMA work), so `frac` is the achieved fraction of the HBM roofline by algorithmic bytes
+        "roofline": {"kernel": "k_accumulate", "bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "limiter": "instruction issue and latency, not bandwidth: the kernel is priced against the HBM roofline (byte streaming, no MFMA work) but its "
                                 "time is set by the VALU / SALU / LDS instructions of the (posting list, doc range) visits - vector ALUs 72 % busy, 46 % of a wave's time in "
@@ -304,6 +357,8 @@ def main():
                      "other_kernels_ms": {kk: float(np.mean([t[kk + "_ms"] for t in roof])) for kk in ("k_select", "k_replay", "k_prep2", "k_stage2", "k_finalize")},
                      "replay_flag_reasons_per_launch": {kk: float(np.mean([t["flag_" + kk] for t in roof])) for kk in ("plateau", "band", "unknown")},
                      "note": "achieved = SURVEY 8(d) algorithmic bytes / k_accumulate duration (HIP events on the launch stream, uncontended launch)"},
+        "roofline_by_kernel": roofline_by_kernel(roof),
+        "planning_lookups": lk,
         "setup_s": {"corpus_gen": t_gen, "index_build_and_upload": t_index, "host_threads": bthreads},
     }
     if stage_ranks is not None:
@@ -311,19 +366,18 @@ def main():
     if flt and not sharded:
         out["config"]["filter"] = flt; out["config"]["facets"] = ["year", "genre"]
         out["filter"] = {"documents_in_filter": in_filter, "first_use_s_incl_compile_and_device_count": t_filter_first_use}
-    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read from inside the process).  The
-    # committed measurement is attached only if it was taken on THIS build of the kernel (sha256 of csrc/stage1.hip.inc) and this workload.
+    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read from inside the process).  The committed
+    # measurement is attached only to the workload it was taken on (config 4, full size, 1000-query batches, one GPU) and only if it was taken on THIS
+    # build of the kernel: sha256 over csrc/stage1.hip.inc AND the launch code of csrc/infidex_hip.hip (launch_acc: grid, block map, LDS size).
     try:
-        import hashlib
-        here = os.path.dirname(os.path.abspath(__file__))
-        pmc = json.load(open(os.path.join(here, "profiles", "r03_pmc.json")))
-        ksha = hashlib.sha256(open(os.path.join(here, "infidex_amd", "csrc", "stage1.hip.inc"), "rb").read()).hexdigest()[:16]
-        if args.docs == full and args.batch == 1000 and not sharded and pmc.get("kernel_source_sha16") == ksha:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        ksha = kernel_sha16()
+        if args.config == 4 and args.docs == full and args.batch == 1000 and not sharded and world == 1 and pmc.get("kernel_source_sha16") == ksha:
             out["roofline"]["traffic"] = pmc["hbm_read_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = "HBM read bytes per launch (FETCH_SIZE x2, " + pmc["source"] + ")"
             out["roofline"]["traffic_frac_of_peak"] = pmc["hbm_read_bytes_per_launch"] / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if acc_ms > 0 else None
         else:
-            out["roofline"]["traffic_note"] = "profiles/r03_pmc.json was measured on another build of the kernel or another workload: not attached"
+            out["roofline"]["traffic_note"] = f"profiles/{PMC_FILE} was measured on another build of the kernel or another workload (config 4 at full size only): not attached"
     except Exception:
         pass
     if want_cpu:
@@ -359,7 +413,7 @@ def main():
         from tests.parity_classify import classify
         cls = classify(eng, o, [texts[i] for i in differ], k) if (differ and not flt) else []
         out["cpu_baseline"] = {"value": sample / secs, "unit": "queries/s", "cores": cthreads, "kind": "port",
-                               "sample": f"first {sample} queries of the first timed batch, same 10M index semantics, one in-flight query per thread; "
+                               "sample": f"first {sample} queries of the first timed batch on the same {args.docs}-document config-{args.config} index, one in-flight query per thread; "
                                          f"oracle = C++ restatement of the reference algorithm (not the .NET binary)",
                                "single_thread_qps": min(sample, 24) / secs1, "single_thread_p50_ms": float(np.median(lat1)),
                                "index_build_s": orc_box["build_s"], "identical_topk_sets": f"{same}/{sample}",

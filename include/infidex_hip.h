@@ -375,6 +375,8 @@ int32_t infx_last_exact_replays(infx_stream* s, uint32_t* n);
  * why3[0] exact plateau (equal first-pass scores on both sides of the cut), [1] the best row left out lies inside the rounding band below the cut,
  * [2] the best row left out was not gathered (flagged conservatively). */
 int32_t infx_last_replay_stats(infx_stream* s, float* ms, uint32_t* why3);
+/* ... and its parts: k_ex_scan, k_ex_chunk (both launches), k_ex_heap, k_exact1 (ms, HIP events on the stream). */
+int32_t infx_last_replay_breakdown(infx_stream* s, float* ms4);
 
 #ifdef __cplusplus
 }

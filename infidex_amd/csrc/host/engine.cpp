@@ -53,6 +53,7 @@ struct Batch {
     std::vector<uint32_t> localIdx;     // local Stage-2 candidates -> position in lastCands
     std::vector<std::shared_ptr<FuzzyUnion>> pending; std::vector<uint32_t> pendingCounts; std::unordered_map<const FuzzyUnion*, uint32_t> unionIdx;   // unions whose df this batch counts
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tPlanPar = 0, tTok = 0, tUnion = 0;
+    double tLd1Dev = 0, tUnionDev = 0;      // of the planning time: spent inside infx_ld1_expand / infx_union_build (device work + the wait for it)
     std::shared_ptr<FusedIn> pre;      // sharded phases: per-query device-pipeline inputs prepared in phase 0 (off the collective path)
 };
 
@@ -62,6 +63,7 @@ struct infx_session {
     Batch* batch = nullptr;
     infx_stream* stream = nullptr;
     double tPrep1 = 0, tStage1 = 0, tPrep2 = 0, tStage2 = 0, tPost = 0;
+    bool kernelTimesPending = false; float msReplayParts[4] = {0, 0, 0, 0};
     float msAcc = 0, msSel = 0, msCov = 0, msPrep2 = 0, msFin = 0, msReplay = 0; uint32_t flagWhy[3] = {0, 0, 0}; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0; uint32_t exactReplays = 0;
     // last-batch introspection for parity tests
     std::vector<QueryPlan> lastPlans;
@@ -83,7 +85,11 @@ struct PlanGate {
     void enter() { if (limit <= 0) return; std::unique_lock<std::mutex> lk(m); const uint64_t t = next++; cv.wait(lk, [&] { return t == serving && inUse < limit; }); serving++; inUse++; cv.notify_all(); }
     void leave() { if (limit <= 0) return; { std::lock_guard<std::mutex> lk(m); inUse--; } cv.notify_all(); }
 };
-struct PlanGateHold { PlanGate& g; explicit PlanGateHold(PlanGate& x) : g(x) { g.enter(); } ~PlanGateHold() { g.leave(); } };
+static thread_local PlanGate* tl_gate = nullptr;      // the gate this thread holds, if any
+struct PlanGateHold { PlanGate& g; explicit PlanGateHold(PlanGate& x) : g(x) { g.enter(); tl_gate = &g; } ~PlanGateHold() { tl_gate = nullptr; g.leave(); } };
+// A planner that waits for the device (LD1 expansion, union cardinalities) gives its place at the gate to the next planner and queues again afterwards: the
+// gate rations CPU time, and a thread blocked on a HIP event uses none (held across the wait it capped the pipeline at `limit` / wait batches per second).
+struct PlanGatePause { PlanGate* g; PlanGatePause() : g(tl_gate) { if (g) g->leave(); } ~PlanGatePause() { if (g) g->enter(); } };
 struct infx_engine {
     // non-indexed document fields (DocumentFields) as dictionary-encoded columns + compiled Infiscript filters (config 5)
     std::vector<filt::Column> columns; std::mutex filterMu; std::unordered_map<std::string, CompiledFilter> filters;
@@ -297,8 +303,10 @@ static int32_t expand_pending(infx_engine* e, infx_session* S, std::vector<Query
     std::vector<uint32_t> offs(nw + 1, 0), counts(nw, 0), status(nw, 2); std::vector<u16> chars; std::vector<int32_t> members((size_t)nw * cap);
     for (uint32_t i = 0; i < nw; i++) { if (words[i]->size() <= 64) chars.insert(chars.end(), words[i]->begin(), words[i]->end()); offs[i + 1] = (uint32_t)chars.size(); }     // longer words: empty -> status 2
     auto t0 = std::chrono::steady_clock::now();
-    int32_t rc = infx_ld1_expand(S->stream, nw, offs.data(), (const uint16_t*)chars.data(), cap, members.data(), counts.data(), status.data());
+    int32_t rc;
+    { PlanGatePause pause; rc = infx_ld1_expand(S->stream, nw, offs.data(), (const uint16_t*)chars.data(), cap, members.data(), counts.data(), status.data()); }
     if (rc) { g_eerr = infx_last_error(); return rc; }
+    S->batch->tLd1Dev = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::vector<uint32_t> onHost;
     for (uint32_t i = 0; i < nw; i++) {
         if (status[i] == 0) made[i] = union_of_matches(ix, members.data() + (size_t)i * cap, std::min(counts[i], cap));
@@ -346,8 +354,11 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
         B.pendingCounts.assign(B.pending.size(), 0);
         std::vector<uint32_t> mo(B.pending.size() + 1, 0); std::vector<int32_t> mm;
         for (size_t v = 0; v < B.pending.size(); v++) { mm.insert(mm.end(), B.pending[v]->members.begin(), B.pending[v]->members.end()); mo[v + 1] = (uint32_t)mm.size(); }
-        int32_t rc = infx_union_build(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), B.pendingCounts.data());
+        const double tu0 = now_ms();
+        int32_t rc;
+        { PlanGatePause pause; rc = infx_union_build(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), B.pendingCounts.data()); }
         if (rc) { g_eerr = infx_last_error(); return rc; }
+        B.tUnionDev = now_ms() - tu0;
     }
     B.tUnion = now_ms() - B.t0;
     return INFX_OK;
@@ -775,6 +786,14 @@ static int32_t fused_inputs_for_phase3(infx_engine* e, infx_session* S, int32_t 
 // Unsharded engines: the whole batch on the device with one synchronisation (infx_search_fused).  The host keeps what needs
 // its dictionaries: text preparation, term lookup, LD1 expansion, idf / roles (ph_plan*), and per query the WordMatcher list
 // descriptors (WordMatcher.Lookup, WordMatcher.cs:95-186) + CoverageEngine.PrepareQuery.
+static void resolve_kernel_times(infx_session* S) {
+    if (!S->kernelTimesPending || !S->stream) return;
+    S->kernelTimesPending = false;
+    float ms5[5] = {0, 0, 0, 0, 0}; infx_last_fused_timings(S->stream, ms5);
+    S->msAcc = ms5[0]; S->msSel = ms5[1]; S->msPrep2 = ms5[2]; S->msCov = ms5[3]; S->msFin = ms5[4];
+    infx_last_replay_stats(S->stream, &S->msReplay, S->flagWhy);
+    infx_last_replay_breakdown(S->stream, S->msReplayParts);
+}
 static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t max_results,
                                   int32_t depth, int32_t enable_coverage, int64_t* out_keys, float* out_scores, uint8_t* out_ties,
                                   uint32_t* out_counts, uint32_t* out_flags) {
@@ -793,10 +812,14 @@ static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, 
                            out_keys, out_scores, out_ties, out_counts, out_flags);
     if (rc) { g_eerr = infx_last_error(); return rc; }
     B.t3 = now_ms();
-    float ms5[5] = {0, 0, 0, 0, 0}; infx_last_fused_timings(S->stream, ms5);
-    S->msAcc = ms5[0]; S->msSel = ms5[1]; S->msPrep2 = ms5[2]; S->msCov = ms5[3]; S->msFin = ms5[4];
+    // Kernel durations are resolved when somebody asks (infx_engine_session_last_timings): every hipEventElapsedTime is a HIP API call that queues behind the
+    // launches of the other sessions (measured: 2.8-3.3 ms of "post" time per batch on two of three boxes with six sessions).
+    S->kernelTimesPending = true;
+    float ms5[5] = {0, 0, 0, 0, 0};
+    static const bool dbgTimes = getenv("INFX_DEBUG") != nullptr;
+    if (dbgTimes) { resolve_kernel_times(S); ms5[0] = S->msAcc; ms5[1] = S->msSel; ms5[2] = S->msPrep2; ms5[3] = S->msCov; ms5[4] = S->msFin; }
     uint64_t s1rows = 0; infx_last_fused_stats(S->stream, &s1rows, &S->s2Candidates, &S->s2TextBytes);
-    infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays); infx_last_replay_stats(S->stream, &S->msReplay, S->flagWhy);
+    infx_last_alg_bytes(S->stream, &S->streamedBytes); infx_last_candidates(S->stream, &S->s1Candidates); infx_last_exact_replays(S->stream, &S->exactReplays);
     {   // B_alg(q) = sum_t df_t * 5 B (4 B for fuzzy virtual terms) + card(C_q) * 4 B + depth * 12 B
         uint64_t ab = 0;
         for (auto& t : B.dterms) ab += t.term_id >= 0 ? (uint64_t)e->shardTermLen(t.term_id) * 5ull : (uint64_t)t.extra_len * 4ull;
@@ -1293,13 +1316,27 @@ int32_t infx_engine_default_session(infx_engine* e, infx_session** out) { if (!e
 int32_t infx_engine_session_last_timings(infx_session* S, double* host_ms5, float* kernel_ms3, uint64_t* alg_bytes3) {
     if (!S) return efail(INFX_EINVAL, "null");
     if (host_ms5) { host_ms5[0] = S->tPrep1; host_ms5[1] = S->tStage1; host_ms5[2] = S->tPrep2; host_ms5[3] = S->tStage2; host_ms5[4] = S->tPost; }
+    if (kernel_ms3) resolve_kernel_times(S);
     if (kernel_ms3) { kernel_ms3[0] = S->msAcc; kernel_ms3[1] = S->msSel; kernel_ms3[2] = S->msCov; kernel_ms3[3] = S->msPrep2; kernel_ms3[4] = S->msFin; }
     if (alg_bytes3) { alg_bytes3[0] = S->algBytes; alg_bytes3[1] = S->s2Candidates; alg_bytes3[2] = S->s2TextBytes; alg_bytes3[3] = S->streamedBytes; alg_bytes3[4] = S->s1Candidates; alg_bytes3[5] = S->exactReplays; }
     return INFX_OK;
 }
 
+int32_t infx_engine_session_replay_breakdown(infx_session* S, float* ms4) {      // k_ex_scan, k_ex_chunk, k_ex_heap, k_exact1 of the last batch (ms)
+    if (!S || !ms4) return INFX_EINVAL;
+    resolve_kernel_times(S);
+    for (int i = 0; i < 4; i++) ms4[i] = S->msReplayParts[i];
+    return INFX_OK;
+}
+int32_t infx_engine_session_plan_breakdown(infx_session* S, double* out4) {      // of the last batch's plan_ms: tokens + term lookups (incl. the LD1 call), of that inside infx_ld1_expand, inside infx_union_build, idf / roles
+    if (!S || !out4 || !S->batch) return INFX_EINVAL;
+    const Batch& B = *S->batch;
+    out4[0] = B.tTok; out4[1] = B.tLd1Dev; out4[2] = B.tUnionDev; out4[3] = B.t1 - B.t0 - B.tUnion;
+    return INFX_OK;
+}
 int32_t infx_engine_session_last_replay(infx_session* S, float* ms, uint32_t* why3) {
     if (!S) return efail(INFX_EINVAL, "null");
+    resolve_kernel_times(S);
     if (ms) *ms = S->msReplay; if (why3) { why3[0] = S->flagWhy[0]; why3[1] = S->flagWhy[1]; why3[2] = S->flagWhy[2]; }
     return INFX_OK;
 }

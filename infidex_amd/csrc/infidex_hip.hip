@@ -248,7 +248,12 @@ struct infx_stream {
     size_t capFDocs = 0, capFacCodes = 0, capFacCounts = 0, capFacN = 0;
     std::vector<uint32_t> hFacCodes, hFacCounts, hFacN; uint32_t facetNq = 0;
     hipStream_t st = nullptr;
+    // Planning kernels (k_ld1, k_union count pass) are tiny and the host WAITS for their results (idf needs the union cardinalities): queued behind the
+    // streaming kernels of the other batches in flight they came back after 10-15 ms (measured: plan_ms 14.9 per batch of which ~2 ms host work).  They
+    // run on a stream of their own with the highest priority the device offers, so their few hundred waves are placed as soon as any CU has room.
+    hipStream_t stPlan = nullptr, stMain = nullptr; hipEvent_t evPlan = nullptr;
     hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1, evX0, evX1, evSync;
+    hipEvent_t evXa, evXb, evXc; bool timedReplayParts = false; float msReplayParts[4] = {0, 0, 0, 0};      // inside the replay: after k_ex_scan, after both k_ex_chunk launches, after k_ex_heap
     bool timedReplay = false; float msReplay = 0.f; uint32_t lastFlagWhy[4] = {0, 0, 0, 0};     // exact replay of the last batch: kernel time, why its queries were flagged
     // fused pipeline workspaces
     void *dFQ = nullptr, *dFLists = nullptr, *dFOwned = nullptr, *dFS1 = nullptr, *dFMeta = nullptr, *dFQueries = nullptr, *dFKeys = nullptr, *dFScores = nullptr, *dFTies = nullptr, *dFCounts = nullptr, *dFFlags = nullptr, *dFErr = nullptr, *dFHitsAll = nullptr, *dFHcAll = nullptr, *dFPairs = nullptr;
@@ -397,6 +402,20 @@ static int32_t downx(infx_stream* s, void* dst, const void* srcDev, size_t bytes
     HIPCHK(hipMemcpyAsync(dst, srcDev, bytes, hipMemcpyDeviceToDevice, s->st)); s->unsynced = true;
     return INFX_OK;
 }
+// Planning calls (infx_ld1_expand, infx_union_build) run on the stream's high-priority companion: every helper above works on s->st, which is swapped
+// for the duration of the call; leave() makes the main stream wait for what the planning stream still has queued (the union write pass).
+struct PlanStream {
+    infx_stream* s; bool on;
+    explicit PlanStream(infx_stream* x) : s(x), on(x->stPlan != nullptr) { if (on) s->st = s->stPlan; }
+    int32_t leave() {
+        if (!on) return INFX_OK;
+        on = false; s->st = s->stMain;
+        HIPCHK(hipEventRecord(s->evPlan, s->stPlan));
+        HIPCHK(hipStreamWaitEvent(s->stMain, s->evPlan, 0));
+        return INFX_OK;
+    }
+    ~PlanStream() { if (on) s->st = s->stMain; }
+};
 #define UPX(dst, src, n) do { int32_t rc_ = upx(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
 #define DOWNX(dst, src, n) do { int32_t rc_ = downx(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
 #define UP(dst, src, n) do { int32_t rc_ = up(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
@@ -564,12 +583,15 @@ static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
     if (fast) {
         ExBufs xb; { int32_t rc_ = exact_chunk_tables(s, nq, xb); if (rc_) return rc_; }
         k_ex_scan<<<nq, EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, nullptr);
+        HIPCHK(hipEventRecord(s->evXa, s->st));
         k_ex_chunk<EXC_SMALL><<<8192, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksSmall, 1, ix->avgdl);
         k_ex_chunk<EXC_BIG><<<2048, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 2, ix->avgdl);
+        HIPCHK(hipEventRecord(s->evXb, s->st));
         static const bool exProf = getenv("INFX_EXACT_PROF") != nullptr;     // k_ex_heap counters (profiling only)
         k_ex_heap<<<nq, WAVE, 0, s->st>>>(ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, s->dExactStat,
                                           exProf ? (unsigned long long*)s->dStats : nullptr);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->evXc, s->st)); s->timedReplayParts = true;
         if (exProf) { unsigned long long h[8]; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 64, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 64);
             if (h[0]) fprintf(stderr, "[infx] k_ex_heap per query over %llu queries: chunks %.0f rows %.0f admitted-or-tested %.0f heap-cycles %.0f total-cycles %.0f\n", h[0],
                               (double)h[5] / h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0]); }
@@ -874,7 +896,15 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     HIPCHK(hipSetDevice(ix->cfg.device));
     infx_stream* s = new infx_stream(); s->ix = ix;
     HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-    hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1, &s->evP0, &s->evP1, &s->evF0, &s->evF1, &s->evX0, &s->evX1};
+    s->stMain = s->st;
+    {
+        static const bool noPrio = [] { const char* e = getenv("INFX_PLAN_PRIORITY"); return e && e[0] == '0'; }();
+        int least = 0, greatest = 0;
+        if (!noPrio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+            hipStreamCreateWithPriority(&s->stPlan, hipStreamNonBlocking, greatest) == hipSuccess) HIPCHK(hipEventCreateWithFlags(&s->evPlan, hipEventDisableTiming));
+        else { (void)hipGetLastError(); s->stPlan = nullptr; }
+    }
+    hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1, &s->evP0, &s->evP1, &s->evF0, &s->evF1, &s->evX0, &s->evX1, &s->evXa, &s->evXb, &s->evXc};
     for (auto e : ev) HIPCHK(hipEventCreate(e));
     HIPCHK(hipEventCreateWithFlags(&s->evSync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
@@ -895,9 +925,11 @@ void infx_stream_destroy(infx_stream* s) {
     if (s->comm && rccl_api().ok) rccl_api().destroy(s->comm);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
-    hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1, s->evP0, s->evP1, s->evF0, s->evF1, s->evX0, s->evX1};
+    hipEvent_t ev[] = {s->evA0, s->evA1, s->evS0, s->evS1, s->evC0, s->evC1, s->evP0, s->evP1, s->evF0, s->evF1, s->evX0, s->evX1, s->evXa, s->evXb, s->evXc};
     for (auto e : ev) hipEventDestroy(e);
     hipEventDestroy(s->evSync);
+    if (s->evPlan) hipEventDestroy(s->evPlan);
+    if (s->stPlan) { hipStreamSynchronize(s->stPlan); hipStreamDestroy(s->stPlan); }
     if (s->st) hipStreamDestroy(s->st);
     delete s;
 }
@@ -1245,6 +1277,7 @@ int32_t infx_ld1_expand(infx_stream* s, uint32_t nwords, const uint32_t* word_of
     if (!ix->haveTrie) return fail(INFX_EINVAL, "infx_upload_term_trie has not been called%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    PlanStream plan(s);
     const size_t nch = word_offs[nwords];
     GROW(s->dLWordOff, s->capLWordOff, ((size_t)nwords + 1) * 4);
     GROW(s->dLChars, s->capLChars, std::max<size_t>(1, nch) * 2);
@@ -1783,6 +1816,7 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    PlanStream plan(s);
     const int nR = ix->d.nRanges;
     if ((uint64_t)nv * nR > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nv * nRanges exceeds the grid limit%s");
     const uint32_t nm = member_offs[nv];
@@ -1807,13 +1841,23 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     UP(s->dUBase, s->unionBase.data(), ((size_t)nv + 1) * 8);
     launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, (const unsigned long long*)s->dUBase, (int32_t*)s->dUDocs);
     HIPCHK(hipGetLastError());
-    return INFX_OK;     // the write pass stays queued on the stream; infx_stage1_accumulate is ordered behind it
+    return plan.leave();     // the write pass stays queued (planning stream); the main stream — infx_stage1_accumulate — is ordered behind it
 }
 int32_t infx_last_replay_stats(infx_stream* s, float* ms, uint32_t* why3) {
     if (!s) return fail(INFX_EINVAL, "null argument%s");
     if (s->timedReplay) { hipEventElapsedTime(&s->msReplay, s->evX0, s->evX1); s->timedReplay = false; }
     if (ms) *ms = s->msReplay;
     if (why3) { why3[0] = s->lastFlagWhy[0]; why3[1] = s->lastFlagWhy[1]; why3[2] = s->lastFlagWhy[2]; }
+    return INFX_OK;
+}
+int32_t infx_last_replay_breakdown(infx_stream* s, float* ms4) {      // k_ex_scan, k_ex_chunk (both launches), k_ex_heap, k_exact1 of the last batch
+    if (!s || !ms4) return fail(INFX_EINVAL, "null argument%s");
+    if (s->timedReplayParts) {
+        hipEventElapsedTime(&s->msReplayParts[0], s->evX0, s->evXa); hipEventElapsedTime(&s->msReplayParts[1], s->evXa, s->evXb);
+        hipEventElapsedTime(&s->msReplayParts[2], s->evXb, s->evXc); hipEventElapsedTime(&s->msReplayParts[3], s->evXc, s->evX1);
+        s->timedReplayParts = false;
+    }
+    for (int i = 0; i < 4; i++) ms4[i] = s->msReplayParts[i];
     return INFX_OK;
 }
 int32_t infx_last_exact_replays(infx_stream* s, uint32_t* n) {

@@ -447,17 +447,26 @@ class Session:
         self.engine._check(self.L.infx_engine_set_filter(self.h, expr.encode() if expr is not None else None, int(enable_facets), C.byref(nin)))
         return int(nin.value)
 
-    def last_timings(self):
+    def last_timings(self, kernels=True):
+        """Host phase times of the session's last batch; kernels=True adds the kernel durations (HIP events on the session's stream).  Resolving those costs a
+        handful of HIP API calls, which queue behind the launches of other sessions: a throughput run asks for them on a sample of its batches only."""
         host = np.zeros(5, np.float64); kern = np.zeros(5, np.float32); alg = np.zeros(6, np.uint64)
-        self.engine._check(self.L.infx_engine_session_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float), _p(alg, C.c_uint64)))
-        rms = C.c_float(0); why = np.zeros(3, np.uint32)
-        self.engine._check(self.L.infx_engine_session_last_replay(self.h, C.byref(rms), _p(why, C.c_uint32)))
-        return {"k_replay_ms": float(rms.value), "flag_plateau": int(why[0]), "flag_band": int(why[1]), "flag_unknown": int(why[2]),
-                "plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
-                "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
-                "k_prep2_ms": float(kern[3]), "k_finalize_ms": float(kern[4]),
-                "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2]),
-                "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4]), "exact_replays": int(alg[5])}
+        self.engine._check(self.L.infx_engine_session_last_timings(self.h, _p(host, C.c_double), _p(kern, C.c_float) if kernels else None, _p(alg, C.c_uint64)))
+        pb = np.zeros(4, np.float64)
+        self.engine._check(self.L.infx_engine_session_plan_breakdown(self.h, _p(pb, C.c_double)))
+        out = {"plan_ms": host[0], "stage1_ms": host[1], "prep2_ms": host[2], "stage2_ms": host[3], "post_ms": host[4],
+               "plan_tokens_ms": float(pb[0]), "plan_ld1_device_ms": float(pb[1]), "plan_union_device_ms": float(pb[2]), "plan_finish_ms": float(pb[3]),
+               "alg_bytes": int(alg[0]), "stage2_candidates": int(alg[1]), "stage2_text_bytes": int(alg[2]),
+               "streamed_bytes": int(alg[3]), "stage1_candidates": int(alg[4]), "exact_replays": int(alg[5])}
+        if kernels:
+            rms = C.c_float(0); why = np.zeros(3, np.uint32); parts = np.zeros(4, np.float32)
+            self.engine._check(self.L.infx_engine_session_last_replay(self.h, C.byref(rms), _p(why, C.c_uint32)))
+            self.engine._check(self.L.infx_engine_session_replay_breakdown(self.h, _p(parts, C.c_float)))
+            out.update({"k_replay_ms": float(rms.value), "flag_plateau": int(why[0]), "flag_band": int(why[1]), "flag_unknown": int(why[2]),
+                        "k_ex_scan_ms": float(parts[0]), "k_ex_chunk_ms": float(parts[1]), "k_ex_heap_ms": float(parts[2]), "k_exact1_ms": float(parts[3]),
+                        "k_accumulate_ms": float(kern[0]), "k_select_ms": float(kern[1]), "k_stage2_ms": float(kern[2]),
+                        "k_prep2_ms": float(kern[3]), "k_finalize_ms": float(kern[4])})
+        return out
 
 
 def normalize(s, lower=False):
