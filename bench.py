@@ -363,6 +363,17 @@ def main():
     }
     if stage_ranks is not None:
         out["stage_ms_per_step_per_rank"] = stage_ranks
+    if sharded:
+        # what every rank issued through the native driver (set-up + warm-up + timed batches): W ranks with equal counts = RCCL saw W ranks in step
+        cs = searcher.coll_stats()
+        cs["batches"] = len(searcher.sessions) + nsteps
+        if dist is not None and world > 1:
+            allcs = [None] * world
+            dist.all_gather_object(allcs, cs)
+        else:
+            allcs = [cs]
+        out["collectives_per_rank"] = allcs
+        out["config"]["collective_order"] = "ring over the pipeline sessions (infx_engine_coll_ring): one collective per turn, same order on every rank"
     if flt and not sharded:
         out["config"]["filter"] = flt; out["config"]["facets"] = ["year", "genre"]
         out["filter"] = {"documents_in_filter": in_filter, "first_use_s_incl_compile_and_device_count": t_filter_first_use}

@@ -118,6 +118,14 @@ int32_t infx_session_comm_rccl(infx_session* s, const void* id128, infx_comm* ou
 int32_t infx_session_sharded_finish(infx_session* s, const infx_comm* comm, int32_t max_results, int32_t enable_coverage,
                                     int64_t* out_keys, float* out_scores, uint8_t* out_ties, uint32_t* out_counts, uint32_t* out_flags);
 
+/* Collective order across a rank's pipeline sessions.  Each session has its own communicator and HIP stream; left alone, the order in which the sessions' host
+ * threads enqueue their collectives — hence the relative order of different communicators' kernels on the device — depends on thread timing and differs between
+ * ranks (the multi-communicator hang).  infx_engine_coll_ring declares the sessions of the coming stream (batch i on sessions[i mod n], the same on every rank):
+ * inside infx_session_sharded_finish they then take turns, one collective per turn, in ring order; a session calls infx_session_coll_retire after its last batch
+ * of the stream.  n = 0: no ordering.  INFX_COLL_ORDER=0 switches it off. */
+int32_t infx_engine_coll_ring(infx_engine* e, uint32_t n, infx_session* const* sessions);
+int32_t infx_session_coll_retire(infx_session* s);
+int32_t infx_session_coll_stats(infx_session* s, uint64_t* out4 /* all-reduce calls, all-gather calls, all-reduce bytes, all-gather bytes; cumulative */);
 int32_t infx_session_phase3(infx_session* s, int32_t nranks, const infx_hit* all_hits, const uint32_t* all_hitcounts, int32_t max_results,
                             int32_t enable_coverage, uint64_t* ncand);
 int32_t infx_session_outs(infx_session* s, int32_t* outs3);

@@ -106,6 +106,9 @@ int32_t infx_comm_allgather(infx_stream* s, const void* send /* device */, void*
 int32_t infx_stream_scratch(infx_stream* s, int32_t slot, uint64_t bytes, void** out);
 int32_t infx_stream_copy(infx_stream* s, void* dst, const void* src, uint64_t bytes);      /* stream-ordered; host pointers are staged; call infx_stream_wait before reading a host destination */
 int32_t infx_stream_fill0(infx_stream* s, void* dev, uint64_t bytes);
+/* After an all-gather of ONE packed block per rank (parts of part_bytes[p] bytes back to back, blocks `stride` bytes apart): dsts[p] receives the nranks
+ * pieces of part p consecutively (rank-major), as separate all-gathers of the parts would have left them.  Device memory: a stream-ordered kernel; host: memcpy. */
+int32_t infx_stream_unpack(infx_stream* s, const void* src, uint64_t stride, int32_t nranks, int32_t nparts /* <= 4 */, const uint64_t* part_bytes, void* const* dsts);
 int32_t infx_stream_wait(infx_stream* s);
 int32_t infx_stream_native(infx_stream* s, void** hip_stream);      /* the hipStream_t the stream's kernels, copies and collectives are ordered on */
 

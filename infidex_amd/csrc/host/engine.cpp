@@ -64,6 +64,7 @@ struct infx_session {
     infx_stream* stream = nullptr;
     double tPrep1 = 0, tStage1 = 0, tPrep2 = 0, tStage2 = 0, tPost = 0;
     bool kernelTimesPending = false; float msReplayParts[4] = {0, 0, 0, 0};
+    uint64_t collCalls[2] = {0, 0}, collBytes[2] = {0, 0};      // all-reduce / all-gather calls and payload bytes this session issued (sharded driver), cumulative
     float msAcc = 0, msSel = 0, msCov = 0, msPrep2 = 0, msFin = 0, msReplay = 0; uint32_t flagWhy[3] = {0, 0, 0}; uint64_t algBytes = 0; uint64_t s2Candidates = 0, s2TextBytes = 0, streamedBytes = 0, s1Candidates = 0; uint32_t exactReplays = 0;
     // last-batch introspection for parity tests
     std::vector<QueryPlan> lastPlans;
@@ -77,6 +78,34 @@ struct infx_session {
 };
 
 struct CompiledFilter { infx_filter* dev = nullptr; uint32_t inFilter = 0; bool counted = false; };
+// Order of the collectives of a rank's pipeline sessions.  Every session has a communicator and a HIP stream of its own, and its host thread enqueues the
+// collectives of its batch when it gets there — left alone, the relative order of DIFFERENT communicators' kernels on a device depends on thread timing and
+// differs from rank to rank, the classic multi-communicator hang (two collective kernels each holding the CUs the other's peer needs).  The ring makes the
+// order a function of the batch schedule alone: the sessions of a stream take turns, one collective per turn, in ring order; a session whose last batch is
+// done leaves the ring (infx_session_coll_retire).  Batch i runs on session i mod K on every rank and a batch issues the same collectives everywhere, so every
+// rank enqueues every communicator's kernels in the same global order.
+struct CollSeq {
+    std::mutex m; std::condition_variable cv;
+    std::vector<infx_session*> ring; std::vector<uint8_t> active; size_t cur = 0;
+    int index_of(const infx_session* S) const { for (size_t i = 0; i < ring.size(); i++) if (ring[i] == S) return (int)i; return -1; }
+    void advance_from(size_t i) {                       // next active member after i (stays on i when it is the only one)
+        for (size_t k = 1; k <= ring.size(); k++) { const size_t j = (i + k) % ring.size(); if (active[j]) { cur = j; return; } }
+        cur = i;
+    }
+    void set_ring(infx_session* const* ss, uint32_t n) { std::lock_guard<std::mutex> lk(m); ring.assign(ss, ss + n); active.assign(n, 1); cur = 0; cv.notify_all(); }
+    bool enter(const infx_session* S) {                 // blocks until it is S's turn; false: S is not (or no longer) in the ring -> unordered
+        std::unique_lock<std::mutex> lk(m);
+        const int i = index_of(S);
+        if (i < 0 || !active[i]) return false;
+        cv.wait(lk, [&] { return cur == (size_t)i || !active[i]; });
+        return active[i] != 0;
+    }
+    void leave(const infx_session* S) { std::lock_guard<std::mutex> lk(m); const int i = index_of(S); if (i >= 0 && cur == (size_t)i) { advance_from((size_t)i); cv.notify_all(); } }
+    void retire(const infx_session* S) {
+        std::lock_guard<std::mutex> lk(m); const int i = index_of(S); if (i < 0 || !active[i]) return;
+        active[i] = 0; if (cur == (size_t)i) advance_from((size_t)i); cv.notify_all();
+    }
+};
 // Host planning of concurrent sessions goes through a FIFO gate of `limit` planners at a time.  Each planner fans out over the whole worker pool; with
 // six sessions planning at once (the start of a stream, or any moment their phases line up) every one of them takes six times as long and the GPU
 // waits for all of them — gated, the first batches reach the device after one planning time and the pipeline fills in order.
@@ -99,6 +128,7 @@ struct infx_engine {
     void retire_filters() { std::lock_guard<std::mutex> lk(filterMu); for (auto& kv : filters) if (kv.second.dev) retiredFilters.push_back(kv.second.dev); filters.clear(); }
     HostIndex ix;
     PlanGate gate;
+    CollSeq collSeq;
     infx_engine_config cfg{};
     infx_index* dev = nullptr;
     bool indexed = false;
@@ -907,6 +937,8 @@ int32_t infx_engine_set_shard(infx_engine* e, int32_t rank, int32_t nranks) {
 int32_t infx_engine_shard_info(infx_engine* e, int32_t* base, int32_t* n) { if (!e) return INFX_EINVAL; if (base) *base = e->shardBase; if (n) *n = e->shardN; return INFX_OK; }
 int32_t infx_session_phase0(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, uint32_t* nunions) {
     if (!S) return efail(INFX_EINVAL, "null session");
+    // the exact cut across shards falls back to a chained sequential replay whose exchanged state is laid out for max_depth entries (infx_shard_replay_chain)
+    if (S->e && S->e->nranks > 1 && depth != S->e->ix.cfg.maxDepth) return efail(INFX_EINVAL, "document shards search with CoverageDepth == the engine's max_depth");
     PlanGateHold hold(S->e->gate);
     int32_t rc = ph_plan(S->e, S, nq, q_arena, q_offs, depth); if (rc) return rc;
     if (nunions) *nunions = (uint32_t)S->batch->pending.size();
@@ -1152,30 +1184,41 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
     if (dev && infx_stream_native(S->stream, &hs) != INFX_OK) return efail(INFX_EINVAL, "device exchange buffers need a session with a GPU stream");
     auto chk = [&](int32_t rc) { if (rc && g_eerr.empty()) g_eerr = infx_last_error(); return rc; };
 #define XCHK(x) do { int32_t rc_ = chk(x); if (rc_) return rc_; } while (0)
-    XBufs X(S, dev);
+    // one turn of the rank's collective ring per collective (CollSeq above); INFX_COLL_ORDER=0 switches the ordering off
+    static const bool orderedEnv = [] { const char* v = getenv("INFX_COLL_ORDER"); return !(v && v[0] == '0'); }();
+    const bool ordered = orderedEnv && comm->nranks > 1;      // a single rank has no peer to fall out of step with (measured cost of the lock-step at W = 1: 12 %)
+    struct Turn { CollSeq& q; const infx_session* S; bool in; Turn(CollSeq& x, const infx_session* s_, bool on) : q(x), S(s_), in(on && x.enter(s_)) {} ~Turn() { if (in) q.leave(S); } };
+    auto all_reduce = [&](void* buf, uint64_t count) { Turn t(e->collSeq, S, ordered); S->collCalls[0]++; S->collBytes[0] += count * 4; return comm->allreduce_sum_u32(cctx, buf, count, hs); };
+    auto all_gather = [&](const void* send, void* recv, uint64_t bytes) { Turn t(e->collSeq, S, ordered); S->collCalls[1]++; S->collBytes[1] += bytes; return comm->allgather(cctx, send, recv, bytes, hs); };
     const uint32_t nq = B.nq; const int depth = B.depth;
+    if (W > 1 && depth != e->ix.cfg.maxDepth) return efail(INFX_EINVAL, "document shards search with CoverageDepth == the engine's max_depth (the chained replay exchanges heaps of max_depth entries)");
+    XBufs X(S, dev);
     // Exchange 1b: global df of the batch's new fuzzy unions (the host needs the values: idf is computed there with the reference's logf)
     std::vector<uint32_t> guc(B.pendingCounts);
     if (!guc.empty()) {
         if (dev) {
             void* d = nullptr; XCHK(X.get(guc.size() * 4, &d, false));
             XCHK(infx_stream_copy(S->stream, d, guc.data(), guc.size() * 4));
-            XCHK(comm->allreduce_sum_u32(cctx, d, guc.size(), hs));
+            XCHK(all_reduce(d, guc.size()));
             XCHK(infx_stream_copy(S->stream, guc.data(), d, guc.size() * 4)); XCHK(infx_stream_wait(S->stream));
-        } else XCHK(comm->allreduce_sum_u32(cctx, guc.data(), guc.size(), hs));
+        } else XCHK(all_reduce(guc.data(), guc.size()));
     }
     static const uint32_t zero = 0;
     // phase 1 + Exchange 1: class histograms (tier decisions need GLOBAL cardinalities, Q11)
     void* counts = nullptr; XCHK(X.get((size_t)std::max<uint32_t>(nq, 1) * INFX_NCLASS * 4, &counts, true));
     uint32_t nd = 0; XCHK(infx_session_phase1x(S, guc.empty() ? &zero : guc.data(), counts, &nd));
-    XCHK(comm->allreduce_sum_u32(cctx, counts, (uint64_t)std::max<uint32_t>(nq, 1) * INFX_NCLASS, hs));
+    XCHK(all_reduce(counts, (uint64_t)std::max<uint32_t>(nq, 1) * INFX_NCLASS));
     // phase 2a + Exchange 2a: first-pass lists, counts, best score left out
     const size_t ndp = std::max<uint32_t>(nd, 1), hitB = ndp * depth * sizeof(infx_hit);
-    void *hits = nullptr, *hc = nullptr, *nxt = nullptr, *ah = nullptr, *ac = nullptr, *an = nullptr;
-    XCHK(X.get(hitB, &hits, true)); XCHK(X.get(ndp * 4, &hc, true)); XCHK(X.get(ndp * 4, &nxt, true));
+    // the three pieces a rank contributes (lists | counts | best scores left out) are one packed block: ONE all-gather, unpacked into the per-piece arrays
+    void *pack = nullptr, *apack = nullptr, *ah = nullptr, *ac = nullptr, *an = nullptr;
+    const size_t packB = hitB + 2 * ndp * 4;
+    XCHK(X.get(packB, &pack, true)); XCHK(X.get(packB * W, &apack, false));
+    void* hits = pack; void* hc = (char*)pack + hitB; void* nxt = (char*)pack + hitB + ndp * 4;
     XCHK(X.get(hitB * W, &ah, false)); XCHK(X.get(ndp * 4 * W, &ac, false)); XCHK(X.get(ndp * 4 * W, &an, false));
     XCHK(infx_session_phase2a(S, counts, hits, hc, nxt));
-    XCHK(comm->allgather(cctx, hits, ah, hitB, hs)); XCHK(comm->allgather(cctx, hc, ac, ndp * 4, hs)); XCHK(comm->allgather(cctx, nxt, an, ndp * 4, hs));
+    XCHK(all_gather(pack, apack, packB));
+    { const uint64_t pb[3] = {hitB, ndp * 4, ndp * 4}; void* const ds3[3] = {ah, ac, an}; XCHK(infx_stream_unpack(S->stream, apack, packB, W, 3, pb, ds3)); }
     // phase 2b + Exchange 2c: this shard's part of the exact replay, packed; padded to the largest blob of the world
     uint64_t blobBytes = 0; XCHK(infx_session_phase2b(S, W, ah, ac, an, &blobBytes));
     uint64_t pad = blobBytes;
@@ -1184,17 +1227,18 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
         if (dev) {
             void* d = nullptr; XCHK(X.get(sz.size() * 4, &d, false));
             XCHK(infx_stream_copy(S->stream, d, sz.data(), sz.size() * 4));
-            XCHK(comm->allreduce_sum_u32(cctx, d, sz.size(), hs));
+            XCHK(all_reduce(d, sz.size()));
             XCHK(infx_stream_copy(S->stream, sz.data(), d, sz.size() * 4)); XCHK(infx_stream_wait(S->stream));
-        } else XCHK(comm->allreduce_sum_u32(cctx, sz.data(), sz.size(), hs));
+        } else XCHK(all_reduce(sz.data(), sz.size()));
         pad = 16ull * *std::max_element(sz.begin(), sz.end());
     }
     void *blob = nullptr, *ab = nullptr; XCHK(X.get(pad, &blob, false)); XCHK(X.get(pad * W, &ab, false));
     XCHK(infx_session_phase2b_blob(S, blob, pad));
-    XCHK(comm->allgather(cctx, blob, ab, pad, hs));
+    XCHK(all_gather(blob, ab, pad));
     // phase 2c + Exchange 2b: owner-side heap; the all-gather of the per-rank final lists
     XCHK(infx_session_phase2c(S, W, ab, pad, hits, hc));
-    XCHK(comm->allgather(cctx, hits, ah, hitB, hs)); XCHK(comm->allgather(cctx, hc, ac, ndp * 4, hs));
+    XCHK(all_gather(pack, apack, hitB + ndp * 4));      // lists | counts, one collective
+    { const uint64_t pb[2] = {hitB, ndp * 4}; void* const ds2[2] = {ah, ac}; XCHK(infx_stream_unpack(S->stream, apack, hitB + ndp * 4, W, 2, pb, ds2)); }
     // queries the parallel replay could not certify (rare): the literal sequential replay, shard after shard
     std::vector<uint32_t> fc((size_t)W * ndp);
     XCHK(infx_stream_copy(S->stream, fc.data(), ac, fc.size() * 4)); XCHK(infx_stream_wait(S->stream));
@@ -1208,9 +1252,9 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
         for (int r = 0; r < W; r++) {
             if (r == comm->rank) XCHK(infx_session_phase2d(S, need.data(), state.data()));
             if (dev) {
-                XCHK(infx_stream_copy(S->stream, ds, state.data(), words * 4)); XCHK(comm->allgather(cctx, ds, da, words * 4, hs));
+                XCHK(infx_stream_copy(S->stream, ds, state.data(), words * 4)); XCHK(all_gather(ds, da, words * 4));
                 XCHK(infx_stream_copy(S->stream, all.data(), da, words * 4 * W)); XCHK(infx_stream_wait(S->stream));
-            } else XCHK(comm->allgather(cctx, state.data(), all.data(), words * 4, hs));
+            } else XCHK(all_gather(state.data(), all.data(), words * 4));
             std::memcpy(state.data(), all.data() + (size_t)r * words, words * 4);          // rank r's continuation is the state of record
         }
         std::vector<infx_hit> fh((size_t)W * ndp * depth);
@@ -1227,12 +1271,24 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
     // phase 3 + the all-reduce of the disjoint Stage-2 rows + phase 4
     void* outs = nullptr; XCHK(X.get((size_t)std::max<uint32_t>(nq, 1) * 2 * depth * sizeof(infx_cov_out), &outs, true));
     XCHK(infx_session_phase3x(S, W, ah, ac, max_results, enable_coverage, outs));
-    XCHK(comm->allreduce_sum_u32(cctx, outs, (uint64_t)std::max<uint32_t>(nq, 1) * 2 * depth * 3, hs));
+    XCHK(all_reduce(outs, (uint64_t)std::max<uint32_t>(nq, 1) * 2 * depth * 3));
     XCHK(infx_session_phase4(S, (const int32_t*)outs, out_keys, out_scores, out_ties, out_counts, out_flags));
 #undef XCHK
     return INFX_OK;
 }
 
+int32_t infx_engine_coll_ring(infx_engine* e, uint32_t n, infx_session* const* sessions) {
+    if (!e || (n && !sessions)) return efail(INFX_EINVAL, "null argument");
+    for (uint32_t i = 0; i < n; i++) if (!sessions[i] || sessions[i]->e != e) return efail(INFX_EINVAL, "a ring session belongs to another engine");
+    e->collSeq.set_ring(sessions, n);
+    return INFX_OK;
+}
+int32_t infx_session_coll_retire(infx_session* S) { if (!S || !S->e) return efail(INFX_EINVAL, "null session"); S->e->collSeq.retire(S); return INFX_OK; }
+int32_t infx_session_coll_stats(infx_session* S, uint64_t* out4) {      // all-reduce calls, all-gather calls, all-reduce bytes, all-gather bytes (cumulative)
+    if (!S || !out4) return efail(INFX_EINVAL, "null argument");
+    out4[0] = S->collCalls[0]; out4[1] = S->collCalls[1]; out4[2] = S->collBytes[0]; out4[3] = S->collBytes[1];
+    return INFX_OK;
+}
 int32_t infx_session_phase3(infx_session* S, int32_t W, const infx_hit* all_hits, const uint32_t* all_counts, int32_t max_results, int32_t enable_coverage, uint64_t* ncand) {
     if (!S || W < 1 || max_results < 1) return efail(INFX_EINVAL, "bad arguments");
     static const bool hostPhases = getenv("INFX_PHASED") != nullptr;

@@ -25,6 +25,8 @@
 #include <unordered_map>
 #include <algorithm>
 #include <mutex>
+#include <chrono>
+#include <thread>
 #include <dlfcn.h>
 #include <rccl/rccl.h>          // types and enums only: the functions are resolved with dlopen (rccl_api)
 #include "../../include/infidex_hip.h"
@@ -302,6 +304,7 @@ struct infx_stream {
     size_t capNext = 0, capPrior = 0, capShBlob = 0, capAllBlobs = 0, capAllNext = 0, capChainState = 0, capChainNeed = 0;
     uint32_t shHead[4] = {0, 0, 0, 0}; uint32_t shNd = 0; int shDepth = 0; bool shSelected = false;
     void* scratch[16] = {}; size_t capScratch[16] = {};      // infx_stream_scratch
+    std::vector<void*> parked;                                // outgrown workspaces of a sharded stream (see grow)
     void *dHugeWs = nullptr, *dHugeCnt = nullptr; size_t capHugeWs = 0, capHugeCnt = 0;      // k_stage2's global-workspace pass
     ncclComm_t comm = nullptr;                                 // infx_stream_comm: this stream's own communicator (several batches in flight per rank)
     void *dLWordOff = nullptr, *dLChars = nullptr, *dLMembers = nullptr, *dLCount = nullptr; size_t capLWordOff = 0, capLChars = 0, capLMembers = 0, capLCount = 0;   // infx_ld1_expand
@@ -315,15 +318,22 @@ static int32_t s2_huge_ready(infx_stream* s) {      // pool + bump counter of th
     if (hipMemsetAsync(s->dHugeCnt, 0, 4, s->st) != hipSuccess) return fail(INFX_EHIP, "hipMemsetAsync failed%s");
     return INFX_OK;
 }
+// hipFree synchronises the whole device.  On a document shard another session's collective may be in flight at that moment — its kernel spins until the peer
+// rank's matching collective runs — while on the peer the roles are swapped (that session inside hipFree, this one's collective spinning): neither rank can
+// enqueue what the other waits for.  Workspaces of sharded streams are therefore never freed while the stream lives: the outgrown buffer is parked on the
+// stream (freed by infx_stream_destroy); growth is geometric, so the parked buffers add up to less than the live one.
+static thread_local infx_stream* tl_stream = nullptr;      // the stream of the API call this thread is in (set by pin_reset)
+static void ws_release(void* p);
 static int32_t grow(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return INFX_OK;
-    if (*p) hipFree(*p);
+    if (*p) { if (tl_stream && tl_stream->ix->nranks > 1) tl_stream->parked.push_back(*p); else hipFree(*p); }
     // a quarter of headroom: batches of one workload differ by a few per cent, and a reallocation (hipFree + hipMalloc synchronise the device) in a
     // stream's second batch would stall every other stream's batch in flight
     size_t n = std::max(need + need / 4 + 4096, *cap * 2);
     if (hipMalloc(p, n) != hipSuccess) { *p = nullptr; *cap = 0; return fail(INFX_ENOMEM, "hipMalloc workspace failed%s"); }
     *cap = n; return INFX_OK;
 }
+static void ws_release(void* p) { if (!p) return; if (tl_stream && tl_stream->ix->nranks > 1) tl_stream->parked.push_back(p); else hipFree(p); }
 #define GROW(p, cap, need) do { int32_t rc_ = grow((void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)
 
 // Stage-2 launches: the register budget of the fast variant is selectable for tuning (INFX_S2_WAVES = 2, 4 or 6 waves per SIMD)
@@ -351,16 +361,33 @@ static void* pin_take(infx_stream* s, size_t bytes) {
     s->pins.push_back({(char*)b, cap, bytes});
     return b;
 }
+static int comm_timeout_s() { static const int v = [] { const char* e = getenv("INFX_COMM_TIMEOUT_S"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 120; }(); return v; }
 static int32_t stream_sync(infx_stream* s) {
     // blocking wait (interrupt-driven) instead of hipStreamSynchronize's busy poll: a waiting host thread must not burn a core of a
     // CPU-quota-limited container while the planner pool of another session (or another rank's process) needs it
     HIPCHK(hipEventRecord(s->evSync, s->st));
+    if (s->ix->nranks > 1 && (s->comm || s->ix->comm)) {
+        // A stream that carries RCCL collectives waits with a deadline: a peer that died or fell out of step leaves the collective kernel spinning for ever,
+        // and an unbounded wait would turn that into a hung job.  INFX_COMM_TIMEOUT_S (default 120) -> INFX_ENCCL.
+        const auto t0 = std::chrono::steady_clock::now(); const double limit = (double)comm_timeout_s();
+        for (unsigned spin = 0;; spin++) {
+            const hipError_t q = hipEventQuery(s->evSync);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return fail(INFX_EHIP, "hipEventQuery: %s", hipGetErrorString(q));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                s->pendingOut.clear();
+                return fail(INFX_ENCCL, "a collective (or the kernels behind it) did not complete within INFX_COMM_TIMEOUT_S seconds: a peer rank is gone or out of step%s");
+            }
+            if (spin < 200) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(spin < 2000 ? 20 : 200));
+        }
+    } else
     HIPCHK(hipEventSynchronize(s->evSync));
     for (auto& d : s->pendingOut) std::memcpy(d.dst, d.src, d.bytes);
     s->pendingOut.clear(); s->unsynced = false;
     return INFX_OK;
 }
 static int32_t pin_reset(infx_stream* s) {     // start of an API call: the staging of the previous call must have been consumed
+    tl_stream = s;
     // Outputs still pending here belong to a call that returned before its own synchronisation (an error path): their destinations
     // (often that call's stack variables) are gone, so they are dropped, never copied.
     s->pendingOut.clear();
@@ -605,6 +632,18 @@ static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
     return INFX_OK;
 }
 
+// An all-gather of one packed block per rank ([part 0 | part 1 | ...], `stride` bytes apart) unpacked into per-part arrays of nranks consecutive pieces:
+// three exchanges of a batch (first-pass lists, their counts, the best scores left out) travel as ONE collective.
+struct UnpackArgs { const uint32_t* src; uint64_t strideW; int32_t nranks, nparts; uint64_t offW[4], lenW[4]; uint32_t* dst[4]; };
+__global__ void k_unpack(UnpackArgs a) {
+    uint64_t per = 0; for (int p = 0; p < a.nparts; p++) per += a.lenW[p];
+    const uint64_t total = per * (uint64_t)a.nranks;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / per; uint64_t w = i % per; int p = 0;
+        while (w >= a.lenW[p]) { w -= a.lenW[p]; p++; }
+        a.dst[p][r * a.lenW[p] + w] = a.src[r * a.strideW + a.offW[p] + w];
+    }
+}
 // ---- RCCL (dlopen) ---------------------------------------------------------------------------------------------------------------------------
 struct RcclApi {
     bool ok = false; const char* why = "";
@@ -858,6 +897,7 @@ int32_t infx_comm_allgather(infx_stream* s, const void* send, void* recv, uint64
 int32_t infx_stream_scratch(infx_stream* s, int32_t slot, uint64_t bytes, void** out) {
     if (!s || !out || slot < 0 || slot >= 16) return fail(INFX_EINVAL, "bad scratch arguments%s");
     HIPCHK(hipSetDevice(s->ix->cfg.device));
+    tl_stream = s;
     if (bytes > s->capScratch[slot]) {
         if (s->unsynced) { int32_t rc_ = stream_sync(s); if (rc_) return rc_; }      // work queued on the old buffer
         GROW(s->scratch[slot], s->capScratch[slot], (size_t)bytes);
@@ -874,6 +914,24 @@ int32_t infx_stream_copy(infx_stream* s, void* dst, const void* src, uint64_t by
     if (sd) return down(s, dst, src, bytes);
     if (s->unsynced) { int32_t rc_ = stream_sync(s); if (rc_) return rc_; }
     std::memcpy(dst, src, bytes); return INFX_OK;
+}
+int32_t infx_stream_unpack(infx_stream* s, const void* src, uint64_t stride, int32_t nranks, int32_t nparts, const uint64_t* part_bytes, void* const* dsts) {
+    if (!s || !src || nranks < 1 || nparts < 1 || nparts > 4 || !part_bytes || !dsts) return fail(INFX_EINVAL, "bad unpack arguments%s");
+    uint64_t tot = 0; for (int p = 0; p < nparts; p++) { if (!dsts[p] || (part_bytes[p] & 3)) return fail(INFX_EINVAL, "unpack parts are whole 32-bit words%s"); tot += part_bytes[p]; }
+    if (tot > stride || (stride & 3)) return fail(INFX_EINVAL, "unpack parts exceed the block%s");
+    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    if (is_device_ptr(src)) {
+        UnpackArgs a{}; a.src = (const uint32_t*)src; a.strideW = stride >> 2; a.nranks = nranks; a.nparts = nparts;
+        uint64_t off = 0; for (int p = 0; p < nparts; p++) { a.offW[p] = off >> 2; a.lenW[p] = part_bytes[p] >> 2; a.dst[p] = (uint32_t*)dsts[p]; off += part_bytes[p]; }
+        const uint64_t words = (tot >> 2) * (uint64_t)nranks;
+        const unsigned blocks = (unsigned)std::min<uint64_t>(4096, (words + 255) / 256);
+        if (blocks) k_unpack<<<blocks, 256, 0, s->st>>>(a);
+        HIPCHK(hipGetLastError()); s->unsynced = true;
+    } else {
+        uint64_t off = 0;
+        for (int p = 0; p < nparts; p++) { for (int r = 0; r < nranks; r++) std::memcpy((char*)dsts[p] + (uint64_t)r * part_bytes[p], (const char*)src + (uint64_t)r * stride + off, part_bytes[p]); off += part_bytes[p]; }
+    }
+    return INFX_OK;
 }
 int32_t infx_stream_fill0(infx_stream* s, void* dev, uint64_t bytes) {
     if (!s || (bytes && !dev)) return fail(INFX_EINVAL, "null argument%s");
@@ -922,6 +980,8 @@ void infx_stream_destroy(infx_stream* s) {
                   s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
+    for (void* p : s->parked) hipFree(p);
+    if (tl_stream == s) tl_stream = nullptr;
     if (s->comm && rccl_api().ok) rccl_api().destroy(s->comm);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
@@ -1030,7 +1090,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     size_t need = (size_t)bound + 64;
     if (need > s->arCap) {
         if (need > ((size_t)1 << 31)) return fail(INFX_ECAPACITY, "candidate superset bound exceeds 2^31 entries; split the batch%s");
-        if (s->arDoc) { hipFree(s->arDoc); hipFree(s->arScore); hipFree(s->arCls); s->arDoc = nullptr; }
+        if (s->arDoc) { ws_release(s->arDoc); ws_release(s->arScore); ws_release(s->arCls); s->arDoc = nullptr; }
         size_t n = std::max(need + need / 4, s->arCap * 2);     // headroom as in grow()
         if (hipMalloc((void**)&s->arDoc, n * 4) != hipSuccess || hipMalloc((void**)&s->arScore, n * 4) != hipSuccess || hipMalloc((void**)&s->arCls, n) != hipSuccess)
             return fail(INFX_ENOMEM, "arena allocation failed%s");
@@ -1039,13 +1099,13 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     // per-row hit masks (2 bits per reference term) for the exact Stage-1 replay: kept when every query of the batch has <= 64 terms
     s->maskWords = !exact_enabled(ix) ? 0 : (maxRef <= 32 ? 1 : (maxRef <= 64 ? 2 : 0));
     if (s->maskWords && s->arCap * (size_t)s->maskWords > s->arMaskCap) {
-        if (s->arMask) { hipFree(s->arMask); s->arMask = nullptr; s->arMaskCap = 0; }
+        if (s->arMask) { ws_release(s->arMask); s->arMask = nullptr; s->arMaskCap = 0; }
         const size_t n = s->arCap * (size_t)s->maskWords;
         if (hipMalloc((void**)&s->arMask, n * 8) != hipSuccess) return fail(INFX_ENOMEM, "arena mask allocation failed%s");
         s->arMaskCap = n;
     }
     if (s->maskWords && s->arCap > s->exCap) {
-        if (s->arExc) { hipFree(s->arExc); hipFree(s->exCand); hipFree(s->exOut); s->arExc = nullptr; s->exCand = nullptr; s->exOut = nullptr; s->exCap = 0; }
+        if (s->arExc) { ws_release(s->arExc); ws_release(s->exCand); ws_release(s->exOut); s->arExc = nullptr; s->exCand = nullptr; s->exOut = nullptr; s->exCap = 0; }
         if (hipMalloc((void**)&s->arExc, s->arCap * 4) != hipSuccess || hipMalloc((void**)&s->exCand, s->arCap * 4) != hipSuccess || hipMalloc((void**)&s->exOut, s->arCap * sizeof(infx_hit)) != hipSuccess)
             return fail(INFX_ENOMEM, "exact-replay workspace allocation failed%s");
         s->exCap = s->arCap;

@@ -470,7 +470,22 @@ class ShardedSearcher:
                                                    _p(ties, C.c_uint8), _p(counts, C.c_uint32), _p(flags, C.c_uint32)))
         return keys, scores, ties, counts, flags
 
+    def _ring(self, n):
+        """Declares the sessions whose collectives the coming batches issue (infx_engine_coll_ring): ring order = session order, identical on every rank."""
+        if not self.native:
+            return
+        hs = (C.c_void_p * max(1, n))(*[self.sessions[k].s.h for k in range(n)])
+        self.sessions[0].e._check(self.sessions[0].L.infx_engine_coll_ring(self.sessions[0].e.h, n, hs))
+
+    def coll_stats(self):
+        """Collectives this rank issued through the native driver so far: calls and payload bytes, summed over the pipeline sessions."""
+        tot = np.zeros(4, np.uint64)
+        for s in self.sessions:
+            o = np.zeros(4, np.uint64); s.L.infx_session_coll_stats(s.s.h, _p(o, C.c_uint64)); tot += o
+        return dict(allreduce_calls=int(tot[0]), allgather_calls=int(tot[1]), allreduce_bytes=int(tot[2]), allgather_bytes=int(tot[3]))
+
     def search_packed(self, arena, offs, max_results=10, depth=500, enable_coverage=True):
+        self._ring(1)
         return self._one(0, arena, offs, max_results, depth, enable_coverage)
 
     def search_stream(self, batches, max_results=10, depth=500, enable_coverage=True, stamps=None, timings=None):
@@ -482,6 +497,7 @@ class ShardedSearcher:
         K = len(self.sessions); n = len(batches)
         done = [threading.Event() for _ in range(n)]; out = [None] * n; err = []
         st = [None] * n; tm = [None] * n
+        self._ring(min(K, n))      # the sessions that take part take turns with their collectives (same order on every rank)
 
         def worker(k):
             try:
@@ -494,8 +510,11 @@ class ShardedSearcher:
                 err.append(ex)
                 for e_ in done:
                     e_.set()
+            finally:
+                if self.native:
+                    self.sessions[k].L.infx_session_coll_retire(self.sessions[k].s.h)      # this session's collectives of the stream are all issued
 
-        ths = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(K)]
+        ths = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(min(K, n))]
         for t in ths:
             t.start()
         for i in range(n):

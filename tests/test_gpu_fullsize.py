@@ -1,0 +1,46 @@
+"""BASELINE configs 2 and 3 at their FULL sizes against the oracle (the other GPU tests exercise their shapes at 20-60 k documents):
+   config 2: 100 000 single-field documents, 2-word exact queries, top-10 — a 1000-query batch, the first 300 queries checked against the oracle;
+   config 3: 1 000 000 two-field documents (title High, description Low), 3-word queries with one fuzzed word, top-20 — a 1000-query batch, 100 checked.
+Identical final DocumentId sets, scores within the 2^-6 quantisation step, order flips only between quantisation-step neighbours
+(tests/parity_classify.py).  Planning runs with the dictionaries on the device (the default), so these are also full-size runs of k_wm / k_ld1."""
+import numpy as np
+import pytest
+
+from infidex_amd import SearchEngine
+from infidex_amd.engine import pack_texts
+from tests import oracle_lib as O
+from tests.parity_classify import assert_final_rows_match_oracle
+from tools.synth import Synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(config, nq, nsample):
+    s = Synth(config)                                   # full size
+    arena, offs = s.docs()
+    e = SearchEngine.create_default(device=0)
+    e.index_flat(None, arena, offs, s.field_weights)
+    assert e.device_lookups()
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    qa, qo = s.queries(nq, qseed=2024 + config)
+    texts = Synth.texts(qa, qo)
+    a, of = pack_texts(texts)
+    k = s.cfg["k"]
+    keys, scores, ties, counts, flags = e.search_packed(a, of, k)
+    again = e.search_packed(a, of, k)
+    assert np.array_equal(keys, again[0]) and np.array_equal(counts, again[3])          # deterministic
+    same, flips = assert_final_rows_match_oracle(keys, scores, counts, o, texts[:nsample], k, what=f"config {config} at {s.cfg['docs']} documents")
+    st = e.lookup_stats()
+    print(f"config {config}: {same} identical order, {flips} near-tie flips of {nsample}; lookups {st}; exact replays in the batch {e.last_timings()['exact_replays']}")
+    assert int((counts > 0).sum()) >= nq * 9 // 10
+    return st
+
+
+def test_config2_at_100k_documents():
+    st = _run(2, 1000, 300)
+    assert st["wm_device"] >= 1900 and st["wm_host"] == 0
+
+
+def test_config3_at_1m_documents():
+    st = _run(3, 1000, 100)
+    assert st["ld1_device"] > 500 and st["ld1_host"] <= 5 and st["wm_host"] == 0
