@@ -437,6 +437,7 @@ np.savez(sys.argv[1], **out)
     from infidex_amd import build as _build
     exp_lib = _build.build_experiments()
     variants = [dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate
+                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0", INFX_ACC_SKIP="32"),  # ... with the query-fastest block map
                 dict(INFX_ACC_V2="1", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate2
                 dict(INFX_ACC_V2="0", INFX_ACC_V3="1", INFX_ACC_V4="0"),                      # k_accumulate3
                 dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="1", INFX_ACC_SUP="2"),    # k_accumulate4, passes of 2 ranges
