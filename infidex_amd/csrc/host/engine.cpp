@@ -137,7 +137,15 @@ struct infx_engine {
     bool keysAreIds = false;
     std::vector<uint8_t> deleted;     // Document.Deleted per global internal id; empty = nothing deleted
     std::atomic<long long> ld1OnHost{0}, ld1OnDevice{0}, wmOnHost{0}, wmOnDevice{0};      // where the planning lookups ran (introspection)
-    bool devLookups = false;          // WordMatcher dictionaries + term trie uploaded: the LD1 / WordMatcher lookups of planning run on the GPU (f3)
+    bool devLookups = false;          // WordMatcher dictionaries + term trie uploaded: the LD1 / WordMatcher lookups of planning can run on the GPU (f3)
+    // Where a batch's lookups run when both sides can do them (same results either way, tests/test_gpu_lookups.py): 2 = always the device
+    // (INFX_DEVICE_LOOKUPS=1), 0 = by cost — the host's dictionaries answer in ~21 us per unknown word and ~7 us per WordMatcher word of one core, the device
+    // kernels cost a fraction of a millisecond of GPU time per batch and one more wait for the device.  A host with cores to spare (one GPU per 16 CPUs, two
+    // words per query) plans faster itself (measured at 10 M documents: 73.8 k against 72.0 k queries/s); three fuzzy words per query saturate it (config 3:
+    // 36 k against 65 k), and so do eight ranks sharing one CPU quota.  The device takes a batch whose estimated host lookup time exceeds a quarter of the
+    // planner threads' time in one typical batch interval (10 ms).
+    int lookupPolicy = 0;
+    bool lookups_on_device(double estThreadMs) const { return devLookups && (lookupPolicy == 2 || estThreadMs > 2.5 * (double)std::max(1, threads)); }
     int threads = 1;
     int buildThreads = 0;             // > 0: threads of the index build only (infx_engine_set_build_threads)
     infx_session* def = nullptr;      // default session (single-caller API)
@@ -246,6 +254,7 @@ static int32_t upload_lookups(infx_engine* e) {
         if (rc) return rc;
     }
     e->devLookups = true;
+    { const char* d = getenv("INFX_DEVICE_LOOKUPS"); e->lookupPolicy = (d && d[0] == '1') ? 2 : 0; }
     return INFX_OK;
 }
 
@@ -333,10 +342,12 @@ static int32_t expand_pending(infx_engine* e, infx_session* S, std::vector<Query
     std::vector<uint32_t> offs(nw + 1, 0), counts(nw, 0), status(nw, 2); std::vector<u16> chars; std::vector<int32_t> members((size_t)nw * cap);
     for (uint32_t i = 0; i < nw; i++) { if (words[i]->size() <= 64) chars.insert(chars.end(), words[i]->begin(), words[i]->end()); offs[i + 1] = (uint32_t)chars.size(); }     // longer words: empty -> status 2
     auto t0 = std::chrono::steady_clock::now();
-    int32_t rc;
-    { PlanGatePause pause; rc = infx_ld1_expand(S->stream, nw, offs.data(), (const uint16_t*)chars.data(), cap, members.data(), counts.data(), status.data()); }
-    if (rc) { g_eerr = infx_last_error(); return rc; }
-    S->batch->tLd1Dev = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (e->lookups_on_device(0.021 * (double)nw)) {
+        int32_t rc;
+        { PlanGatePause pause; rc = infx_ld1_expand(S->stream, nw, offs.data(), (const uint16_t*)chars.data(), cap, members.data(), counts.data(), status.data()); }
+        if (rc) { g_eerr = infx_last_error(); return rc; }
+        S->batch->tLd1Dev = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }      // else: status stays 2 for every word -> the host walk below, spread over the planner threads
     std::vector<uint32_t> onHost;
     for (uint32_t i = 0; i < nw; i++) {
         if (status[i] == 0) made[i] = union_of_matches(ix, members.data() + (size_t)i * cap, std::min(counts[i], cap));
@@ -362,7 +373,7 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
     g_eerr.clear();
     B.t0 = now_ms();
     std::vector<QueryPlan>& plans = S->lastPlans; plans.assign(nq, QueryPlan());
-    const bool devLd1 = e->devLookups;
+    const bool devLd1 = e->devLookups;      // unknown words are collected per batch; who expands them is decided once their number is known
     parallel_dyn(nq, threads, devLd1 ? 8 : 1, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; i++) plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i], false, devLd1);
     });
@@ -757,7 +768,11 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
     fq.assign(nq, infx_fused_query{}); cq.assign(nq, infx_cov_query{});
     std::vector<std::vector<infx_wm_list>> qLists(nq); std::vector<std::vector<int32_t>> qOwned(nq);
     std::vector<int32_t> covErr(nq, 0);
-    const bool devWm = e->devLookups && ix.cfg.wordMatcher;
+    bool devWm = e->devLookups && ix.cfg.wordMatcher;
+    if (devWm) {      // ~2.5 looked-up words per query: estimated from the batch's text volume (one word per ~7 characters), 7 us of one core each
+        size_t chars = 0; for (uint32_t i = 0; i < nq; i++) chars += plans[i].searchText.size();
+        devWm = e->lookups_on_device(0.007 * (double)chars / 7.0);
+    }
     std::atomic<long long> nDev{0}, nHost{0};
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         WmResult wm;

@@ -178,6 +178,8 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 // experiments, not product: they are compiled only into the library tests/test_gpu_parity.py::test_accumulate_designs_agree_bit_for_bit builds
 // (-DINFX_BUILD_EXPERIMENTS, infidex_amd/build.py build_experiments) and selected there with INFX_ACC_V2 / _V3 / _V4.
 #ifdef INFX_BUILD_EXPERIMENTS
+#define ACC_SR_DEFAULT 0
+#include "stage1s.hip.inc"      // k_accumulate_sr (round 4): container-wide bitmap test + mailbox for sparse (query, container) pairs; bit-identical, not faster
 #include "stage1b.hip.inc"
 #define ACC_V3_DEFAULT 0
 #include "stage1c.hip.inc"
@@ -278,6 +280,7 @@ struct infx_stream {
     struct PendingOut { void* dst; const void* src; size_t bytes; }; std::vector<PendingOut> pendingOut; bool unsynced = false;
     std::vector<uint32_t> unionCount; std::vector<unsigned long long> unionBase{0};   // device-resident unions of the last infx_union_build
     void* dCounts = nullptr; size_t capCounts = 0;
+    void* dDense = nullptr; size_t capDense = 0; bool useSr = false;      // k_accumulate_sr -> k_accumulate hand-over flags, one byte per (query, container)
     void* dCovQ = nullptr; size_t capCovQ = 0;
     void* dCovC = nullptr; size_t capCovC = 0;
     void* dCovO = nullptr; size_t capCovO = 0;
@@ -561,12 +564,32 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
     const int stripe = acc_stripe();
     const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
     const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
+    // sparse (query, container) pairs first (k_accumulate_sr raises dDense for the pairs it leaves to k_accumulate); needs packed postings and stripes inside one container
+    const uint8_t* dense = nullptr; int nSuper = 0;
+#ifdef INFX_BUILD_EXPERIMENTS
+    if (s->useSr && s->dDense && s->ix->d.packed && (65536 / R) % stripe == 0) {
+        constexpr int RPC = 65536 / R;
+        nSuper = (s->ix->d.nRanges + RPC - 1) / RPC;
+        const size_t ldsS = (size_t)(SRA_WORDS + 2) * 6 + SRA_CAP + 64 + INFX_NCLASS * 4 + SRA_CAP * 2 + (size_t)RPC * 4 + 16;
+        const uint64_t blocksS = (uint64_t)nq * 8u * ((nSuper + 7) / 8);
+        static const bool okS = [] { hipFuncAttributes a{}, b2{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate_sr<R, 1>) == hipSuccess && a.sharedSizeBytes == 0 &&
+                                                                      hipFuncGetAttributes(&b2, (const void*)k_accumulate_sr<R, 2>) == hipSuccess && b2.sharedSizeBytes == 0; }();
+        if (okS && blocksS <= 0x7FFFFFFFull) {
+            hipMemsetAsync(s->dDense, 0, (size_t)nq * nSuper, s->st);
+            if (ar.maskWords == 2)
+                k_accumulate_sr<R, 2><<<dim3((unsigned)blocksS), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, (uint8_t*)s->dDense, nSuper, dbgSkip);
+            else
+                k_accumulate_sr<R, 1><<<dim3((unsigned)blocksS), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, (uint8_t*)s->dDense, nSuper, dbgSkip);
+            dense = (const uint8_t*)s->dDense;
+        }
+    }
+#endif
     if (ar.maskWords == 2)
         k_accumulate<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats);
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nSuper);
     else
         k_accumulate<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats);
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nSuper);
     if (dbgSkip & 8) { unsigned long long h[4] = {0, 0, 0, 0}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 32, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 32);
         fprintf(stderr, "[infx] k_accumulate stats: %llu blocks with candidates of %llu, %.2f rounds/block, %.1f candidates/block\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0); }
 }
@@ -977,7 +1000,7 @@ void infx_stream_destroy(infx_stream* s) {
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
                   s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters,
-                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount};
+                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount, s->dDense};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
     for (void* p : s->parked) hipFree(p);
@@ -1122,6 +1145,16 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * 4);        // qCursor
     GROW(s->dQBytes, s->capQBytes, (size_t)nq * 8);
     GROW(s->dCounts, s->capCounts, (size_t)nq * INFX_NCLASS * 4);
+    {   // k_accumulate_sr's per-(query, container) hand-over flags (INFX_ACC_SR=0: everything through k_accumulate)
+#ifdef INFX_BUILD_EXPERIMENTS
+        static const bool sr = [] { const char* e = getenv("INFX_ACC_SR"); return ACC_SR_DEFAULT ? !(e && e[0] == '0') : (e && e[0] == '1'); }();
+#else
+        static const bool sr = false;
+#endif
+        if (sr) GROW(s->dDense, s->capDense, (size_t)nq * ((size_t)ix->d.nRanges + 1)); else { s->dDense = s->capDense ? s->dDense : nullptr; if (!s->capDense) s->dDense = nullptr; }
+        if (!sr && s->dDense) { /* switched off at run time: keep the buffer, do not use it */ }
+        s->useSr = sr;
+    }
     for (size_t i = 0; i < dt.size(); i++) if (termOfEntry[i] >= 0) dt[i].skip = ix->hSkipIdx[termOfEntry[i]];
 
     UP(s->dQueries, dq.data(), nq * sizeof(DevQuery));

@@ -438,6 +438,8 @@ np.savez(sys.argv[1], **out)
     exp_lib = _build.build_experiments()
     variants = [dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate
                 dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0", INFX_ACC_SKIP="32"),  # ... with the query-fastest block map
+                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0", INFX_ACC_SR="1"),     # k_accumulate_sr for the sparse containers + k_accumulate for the rest
+                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0", INFX_ACC_SR="0"),     # ... switched off
                 dict(INFX_ACC_V2="1", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate2
                 dict(INFX_ACC_V2="0", INFX_ACC_V3="1", INFX_ACC_V4="0"),                      # k_accumulate3
                 dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="1", INFX_ACC_SUP="2"),    # k_accumulate4, passes of 2 ranges
