@@ -181,6 +181,21 @@ int32_t infx_engine_delete_documents(infx_engine* e, const int64_t* keys, int64_
  * checked3 (optional): documents, stored terms compared, stored postings compared.  INFX_EUNSUPPORTED when the stored postings are not what the
  * builder produces for the stored texts (e.g. written from differently weighted fields); INFX_EINVAL for a foreign or corrupted file. */
 int32_t infx_engine_load_index(infx_engine* e, const char* path, int64_t* checked3);
+/* SearchEngine.Flush's on-disk segments (INFS: Indexing/Segments/SegmentWriter.cs:13-94, BlockPostingsWriter.cs:24-161 — blocks of 64..256 delta-coded postings
+ * with min / max doc and max weight per block, Compression/GroupVarInt.cs, the "FST2" term tries, Elias-Fano list offsets).  infx_segment_open reads and
+ * VALIDATES a file (every offset, the skip tables against the decoded blocks, the tries against each other, the Elias-Fano select index); infx_segment_export hands its
+ * content over as CSR in ordinal term order — term texts (UTF-16 arena + offsets) and, per term, ascending segment-local doc ids with their weight bytes: the layout
+ * infx_upload_postings takes (map the ordinals to the host's term ids first).  Any output pointer may be NULL. */
+typedef struct infx_segment infx_segment;
+int32_t infx_segment_open(const char* path, infx_segment** out);
+void    infx_segment_close(infx_segment* seg);
+int32_t infx_segment_info(infx_segment* seg, int32_t* doc_count, int32_t* num_terms, int64_t* num_postings, int64_t* term_chars);
+int32_t infx_segment_export(infx_segment* seg, uint32_t* term_offs /* T+1 */, uint16_t* term_chars, uint64_t* post_offs /* T+1 */, int32_t* doc_ids, uint8_t* weights);
+/* A flushed segment against the engine's index of the same documents: the segment covers the documents [doc_base, doc_base + its docCount) (VectorModel.Flush writes
+ * ids relative to the documents flushed before, VectorModel.cs:804-815).  Every term of the segment must exist in the index with exactly the segment's (document,
+ * weight) postings inside that range, and every index term with postings in the range must be in the segment.  checked3 (optional): documents, terms, postings
+ * compared.  INFX_EINVAL for a foreign or corrupted file, INFX_EUNSUPPORTED when segment and index disagree. */
+int32_t infx_engine_verify_segment(infx_engine* e, const char* path, int32_t doc_base, int64_t* checked3);
 int32_t infx_engine_restore_documents(infx_engine* e);      /* clears every Deleted flag */
 /* One host-index build per node instead of one per rank (document shards: every process needs the whole host index — global df / avgdl / N, the term and
  * word dictionaries, the WordMatcher lists).  The node's leader indexes the documents (infx_engine_set_build_threads lets that build use every

@@ -9,6 +9,7 @@
 #include "query.h"
 #include "filter.h"
 #include "infdx2.h"
+#include "infs.h"
 #include "hostcache.h"
 #include <mutex>
 #include <condition_variable>
@@ -1661,9 +1662,70 @@ int32_t infx_engine_load_index(infx_engine* e, const char* path, int64_t* checke
             if (ix.terms.doc[b + i] != t.docs[i] || ix.terms.w[b + i] != t.w[i]) return efail(INFX_EUNSUPPORTED, "a stored posting (document, weight) differs from the rebuilt index: the file was not written from single Med-weight fields");
         nterms++; npost += (int64_t)t.docs.size();
     }
+    {   // ... and the other direction: the rebuilt index may not hold non-stop terms the file lacks (e.g. a file written with another stop-term limit)
+        int64_t built = 0; for (size_t id = 0; id < ix.terms.K(); id++) if (ix.df[id] > 0) built++;
+        if (built != nterms) return efail(INFX_EUNSUPPORTED, "the index rebuilt from the stored documents holds another number of non-stop terms than the file");
+    }
     std::vector<int64_t> gone; for (auto& d : F.docs) if (d.deleted) gone.push_back(d.key);
     if (!gone.empty()) { rc = infx_engine_delete_documents(e, gone.data(), (int64_t)gone.size(), nullptr); if (rc) return rc; }
     if (checked3) { checked3[0] = n; checked3[1] = nterms; checked3[2] = npost; }
+    return INFX_OK;
+}
+
+// ---- INFS segment files (host/infs.h): SearchEngine.Flush's on-disk segments -------------------------------------------------------------------
+struct infx_segment { infs::Segment S; };
+int32_t infx_segment_open(const char* path, infx_segment** out) {
+    if (!path || !out) return efail(INFX_EINVAL, "null argument");
+    infx_segment* g = new infx_segment();
+    if (!infs::read_file(path, g->S)) { const std::string m = g->S.error; delete g; return efail(INFX_EINVAL, "INFS segment: " + m); }
+    *out = g; return INFX_OK;
+}
+void infx_segment_close(infx_segment* g) { delete g; }
+int32_t infx_segment_info(infx_segment* g, int32_t* doc_count, int32_t* num_terms, int64_t* num_postings, int64_t* term_chars) {
+    if (!g) return efail(INFX_EINVAL, "null segment");
+    if (doc_count) *doc_count = g->S.docCount; if (num_terms) *num_terms = (int32_t)g->S.terms.size(); if (num_postings) *num_postings = (int64_t)g->S.doc.size();
+    if (term_chars) { int64_t c = 0; for (auto& t : g->S.terms) c += (int64_t)t.size(); *term_chars = c; }
+    return INFX_OK;
+}
+int32_t infx_segment_export(infx_segment* g, uint32_t* term_offs, uint16_t* term_chars, uint64_t* post_offs, int32_t* doc_ids, uint8_t* weights) {
+    if (!g) return efail(INFX_EINVAL, "null segment");
+    const infs::Segment& S = g->S; const size_t T = S.terms.size();
+    if (term_offs) { uint32_t o = 0; for (size_t t = 0; t < T; t++) { term_offs[t] = o; if (term_chars) std::memcpy(term_chars + o, S.terms[t].data(), S.terms[t].size() * 2); o += (uint32_t)S.terms[t].size(); } term_offs[T] = o; }
+    if (post_offs) std::memcpy(post_offs, S.off.data(), (T + 1) * 8);
+    if (doc_ids && !S.doc.empty()) std::memcpy(doc_ids, S.doc.data(), S.doc.size() * 4);
+    if (weights && !S.w.empty()) std::memcpy(weights, S.w.data(), S.w.size());
+    return INFX_OK;
+}
+int32_t infx_engine_verify_segment(infx_engine* e, const char* path, int32_t doc_base, int64_t* checked3) {
+    if (!e || !path || doc_base < 0) return efail(INFX_EINVAL, "bad arguments");
+    if (!e->indexed) return efail(INFX_EINVAL, "index the documents first: a segment holds postings, not documents");
+    infs::Segment S;
+    if (!infs::read_file(path, S)) return efail(INFX_EINVAL, "INFS segment: " + S.error);
+    const HostIndex& ix = e->ix;
+    if ((int64_t)doc_base + S.docCount > ix.N) return efail(INFX_EUNSUPPORTED, "the segment's documents [doc_base, doc_base + docCount) lie outside the indexed corpus");
+    const int32_t lo = doc_base, hi = doc_base + S.docCount;
+    int64_t npost = 0;
+    for (size_t t = 0; t < S.terms.size(); t++) {
+        const int64_t id = ix.terms.keys.find(uview((const u16*)S.terms[t].data(), S.terms[t].size()));
+        if (id < 0) return efail(INFX_EUNSUPPORTED, "a term of the segment does not exist in the index built from the documents");
+        const int32_t* p = ix.terms.doc.data(); const uint64_t b = ix.terms.off[id], z = ix.terms.off[id + 1];
+        const uint64_t a = std::lower_bound(p + b, p + z, lo) - p, c = std::lower_bound(p + a, p + z, hi) - p;
+        const uint64_t n = S.off[t + 1] - S.off[t];
+        if (c - a != n) return efail(INFX_EUNSUPPORTED, "a term's posting count inside the segment's document range differs from the index");
+        for (uint64_t i = 0; i < n; i++)
+            if (p[a + i] != S.doc[S.off[t] + i] + doc_base || ix.terms.w[a + i] != S.w[S.off[t] + i]) return efail(INFX_EUNSUPPORTED, "a posting (document, weight) of the segment differs from the index");
+        npost += (int64_t)n;
+    }
+    // the other direction: every index term with postings in the range must be in the segment (SegmentWriter keeps the terms with DocumentFrequency > 0)
+    int64_t present = 0;
+    for (size_t id = 0; id < ix.terms.K(); id++) {
+        if (ix.df[id] <= 0) continue;
+        const int32_t* p = ix.terms.doc.data(); const uint64_t b = ix.terms.off[id], z = ix.terms.off[id + 1];
+        const uint64_t a = std::lower_bound(p + b, p + z, lo) - p;
+        if (a < z && p[a] < hi) present++;
+    }
+    if (present != (int64_t)S.terms.size()) return efail(INFX_EUNSUPPORTED, "the index holds terms with postings in the segment's document range that the segment lacks");
+    if (checked3) { checked3[0] = S.docCount; checked3[1] = (int64_t)S.terms.size(); checked3[2] = npost; }
     return INFX_OK;
 }
 

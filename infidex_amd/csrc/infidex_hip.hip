@@ -256,6 +256,7 @@ struct infx_stream {
     // streaming kernels of the other batches in flight they came back after 10-15 ms (measured: plan_ms 14.9 per batch of which ~2 ms host work).  They
     // run on a stream of their own with the highest priority the device offers, so their few hundred waves are placed as soon as any CU has room.
     hipStream_t stPlan = nullptr, stMain = nullptr; hipEvent_t evPlan = nullptr;
+    hipStream_t stAux = nullptr; hipEvent_t evJoin = nullptr;      // the replay's two k_ex_chunk launches run side by side (both are tail-bound: one wave per chunk)
     hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1, evX0, evX1, evSync;
     hipEvent_t evXa, evXb, evXc; bool timedReplayParts = false; float msReplayParts[4] = {0, 0, 0, 0};      // inside the replay: after k_ex_scan, after both k_ex_chunk launches, after k_ex_heap
     bool timedReplay = false; float msReplay = 0.f; uint32_t lastFlagWhy[4] = {0, 0, 0, 0};     // exact replay of the last batch: kernel time, why its queries were flagged
@@ -634,8 +635,14 @@ static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
         ExBufs xb; { int32_t rc_ = exact_chunk_tables(s, nq, xb); if (rc_) return rc_; }
         k_ex_scan<<<nq, EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, nullptr);
         HIPCHK(hipEventRecord(s->evXa, s->st));
+        // the chunks of <= 16 tiles and the longer ones come from two task lists and write disjoint rows: the second launch runs beside the first on the
+        // stream's auxiliary stream (each ends in a tail of a few long chunks: one after the other cost 2.1 + 1.6 ms)
+        hipStream_t bigSt = s->st;
+        if (s->stAux && s->st == s->stMain) { HIPCHK(hipStreamWaitEvent(s->stAux, s->evXa, 0)); bigSt = s->stAux; }
+        k_ex_chunk<EXC_BIG><<<2048, WAVE, 0, bigSt>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 2, ix->avgdl);
+        if (bigSt != s->st) HIPCHK(hipEventRecord(s->evJoin, bigSt));
         k_ex_chunk<EXC_SMALL><<<8192, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksSmall, 1, ix->avgdl);
-        k_ex_chunk<EXC_BIG><<<2048, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 2, ix->avgdl);
+        if (bigSt != s->st) HIPCHK(hipStreamWaitEvent(s->st, s->evJoin, 0));
         HIPCHK(hipEventRecord(s->evXb, s->st));
         static const bool exProf = getenv("INFX_EXACT_PROF") != nullptr;     // k_ex_heap counters (profiling only)
         k_ex_heap<<<nq, WAVE, 0, s->st>>>(ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, s->dExactStat,
@@ -985,6 +992,11 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
             hipStreamCreateWithPriority(&s->stPlan, hipStreamNonBlocking, greatest) == hipSuccess) HIPCHK(hipEventCreateWithFlags(&s->evPlan, hipEventDisableTiming));
         else { (void)hipGetLastError(); s->stPlan = nullptr; }
     }
+    {
+        static const bool noAux = [] { const char* e = getenv("INFX_REPLAY_AUX"); return e && e[0] == '0'; }();
+        if (!noAux && hipStreamCreateWithFlags(&s->stAux, hipStreamNonBlocking) == hipSuccess) HIPCHK(hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming));
+        else { (void)hipGetLastError(); s->stAux = nullptr; }
+    }
     hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1, &s->evP0, &s->evP1, &s->evF0, &s->evF1, &s->evX0, &s->evX1, &s->evXa, &s->evXb, &s->evXc};
     for (auto e : ev) HIPCHK(hipEventCreate(e));
     HIPCHK(hipEventCreateWithFlags(&s->evSync, hipEventBlockingSync | hipEventDisableTiming));
@@ -1012,6 +1024,8 @@ void infx_stream_destroy(infx_stream* s) {
     for (auto e : ev) hipEventDestroy(e);
     hipEventDestroy(s->evSync);
     if (s->evPlan) hipEventDestroy(s->evPlan);
+    if (s->evJoin) hipEventDestroy(s->evJoin);
+    if (s->stAux) { hipStreamSynchronize(s->stAux); hipStreamDestroy(s->stAux); }
     if (s->stPlan) { hipStreamSynchronize(s->stPlan); hipStreamDestroy(s->stPlan); }
     if (s->st) hipStreamDestroy(s->st);
     delete s;
