@@ -260,11 +260,13 @@ def main():
                     ts = time.time()
                     keys, scores, ties, counts, flags = sess.search_packed(batches[s][0], batches[s][1], k, 500)
                     lat[s] = (time.time() - ts) * 1000.0
+                    stampsT[s] = (sessions.index(sess), ts, time.time())
                     tim[s] = sess.last_timings(kernels=(s % 4 == 0))      # kernel durations on every fourth batch: resolving them is HIP API traffic
                     results[s] = (keys, counts)
             except Exception as ex:  # noqa: BLE001
                 errors.append(ex)
 
+        stampsT = [None] * nsteps
         t_start = time.time()
         ths = [threading.Thread(target=worker, args=(se,)) for se in sessions]
         for t in ths:
@@ -273,6 +275,10 @@ def main():
             t.join()
         if errors:
             raise errors[0]
+        if os.environ.get("INFX_BENCH_TIMELINE") == "1":       # per batch: session, submit and completion time (ms from the start of the timed region), host plan / device wait
+            for i in range(args.warmup, nsteps):
+                se_, a_, b_ = stampsT[i]
+                print(f"[timeline] batch {i - args.warmup:3d} session {se_} submit {1000 * (a_ - t_start):7.1f} done {1000 * (b_ - t_start):7.1f} plan {tim[i]['plan_ms']:5.1f} wait {tim[i]['stage2_ms']:5.1f}", file=sys.stderr)
         tim = tim[args.warmup:]
         lat = lat[args.warmup:]
         first_keys = (results[args.warmup][0].copy(), results[args.warmup][1].copy())

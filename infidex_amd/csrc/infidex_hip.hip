@@ -322,22 +322,27 @@ static int32_t s2_huge_ready(infx_stream* s) {      // pool + bump counter of th
     if (hipMemsetAsync(s->dHugeCnt, 0, 4, s->st) != hipSuccess) return fail(INFX_EHIP, "hipMemsetAsync failed%s");
     return INFX_OK;
 }
-// hipFree synchronises the whole device.  On a document shard another session's collective may be in flight at that moment — its kernel spins until the peer
-// rank's matching collective runs — while on the peer the roles are swapped (that session inside hipFree, this one's collective spinning): neither rank can
-// enqueue what the other waits for.  Workspaces of sharded streams are therefore never freed while the stream lives: the outgrown buffer is parked on the
-// stream (freed by infx_stream_destroy); growth is geometric, so the parked buffers add up to less than the live one.
+// hipFree synchronises the whole device: it returns when EVERY stream has drained.  With several sessions in flight the others keep refilling the device, so a
+// session that outgrows a workspace in the middle of a stream waited in hipFree until the run ended (measured, round 4: one batch of a 20-batch run 12 % larger
+// than its session's earlier batches sat 290 ms in grow() — 310 ms instead of 250 ms for the run); and on a document shard another session's collective may be
+// in flight at that moment, spinning until the peer rank's matching collective runs, while on the peer the roles are swapped: neither rank can enqueue what the
+// other waits for.  Workspaces are therefore never freed while their stream lives: the outgrown buffer is parked on the stream (freed by infx_stream_destroy);
+// growth is geometric, so the parked buffers add up to less than the live one.
 static thread_local infx_stream* tl_stream = nullptr;      // the stream of the API call this thread is in (set by pin_reset)
 static void ws_release(void* p);
 static int32_t grow(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return INFX_OK;
-    if (*p) { if (tl_stream && tl_stream->ix->nranks > 1) tl_stream->parked.push_back(*p); else hipFree(*p); }
+    if (*p) { if (tl_stream) tl_stream->parked.push_back(*p); else hipFree(*p); }
     // a quarter of headroom: batches of one workload differ by a few per cent, and a reallocation (hipFree + hipMalloc synchronise the device) in a
     // stream's second batch would stall every other stream's batch in flight
     size_t n = std::max(need + need / 4 + 4096, *cap * 2);
+    static const bool dbgGrow = getenv("INFX_DEBUG_GROW") != nullptr;
+    const auto tg0 = std::chrono::steady_clock::now();
     if (hipMalloc(p, n) != hipSuccess) { *p = nullptr; *cap = 0; return fail(INFX_ENOMEM, "hipMalloc workspace failed%s"); }
+    if (dbgGrow) fprintf(stderr, "[infx] grow: %zu -> %zu bytes (need %zu), hipMalloc took %.2f ms\n", *cap, n, need, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count());
     *cap = n; return INFX_OK;
 }
-static void ws_release(void* p) { if (!p) return; if (tl_stream && tl_stream->ix->nranks > 1) tl_stream->parked.push_back(p); else hipFree(p); }
+static void ws_release(void* p) { if (!p) return; if (tl_stream) tl_stream->parked.push_back(p); else hipFree(p); }
 #define GROW(p, cap, need) do { int32_t rc_ = grow((void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)
 
 // Stage-2 launches: the register budget of the fast variant is selectable for tuning (INFX_S2_WAVES = 2, 4 or 6 waves per SIMD)
@@ -370,7 +375,8 @@ static int32_t stream_sync(infx_stream* s) {
     // blocking wait (interrupt-driven) instead of hipStreamSynchronize's busy poll: a waiting host thread must not burn a core of a
     // CPU-quota-limited container while the planner pool of another session (or another rank's process) needs it
     HIPCHK(hipEventRecord(s->evSync, s->st));
-    if (s->ix->nranks > 1 && (s->comm || s->ix->comm)) {
+    static const bool pollAlways = [] { const char* e = getenv("INFX_SYNC_POLL"); return e && e[0] == '1'; }();
+    if (pollAlways || (s->ix->nranks > 1 && (s->comm || s->ix->comm))) {
         // A stream that carries RCCL collectives waits with a deadline: a peer that died or fell out of step leaves the collective kernel spinning for ever,
         // and an unbounded wait would turn that into a hung job.  INFX_COMM_TIMEOUT_S (default 120) -> INFX_ENCCL.
         const auto t0 = std::chrono::steady_clock::now(); const double limit = (double)comm_timeout_s();
@@ -1128,7 +1134,11 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     if (need > s->arCap) {
         if (need > ((size_t)1 << 31)) return fail(INFX_ECAPACITY, "candidate superset bound exceeds 2^31 entries; split the batch%s");
         if (s->arDoc) { ws_release(s->arDoc); ws_release(s->arScore); ws_release(s->arCls); s->arDoc = nullptr; }
-        size_t n = std::max(need + need / 4, s->arCap * 2);     // headroom as in grow()
+        // The bound (sum of the candidate-generating lists' lengths) varies by +-30 % between 1000-query batches of one workload, and a reallocation in the
+        // middle of a stream is not free even without hipFree (a multi-GB hipMalloc can wait for the device): twice the first batch's need, doubling after that.
+        // ~40 B per row: 5 GB per session at 10 M documents, of 288.
+        size_t n = std::max(need * 2, s->arCap * 2);
+        if (getenv("INFX_DEBUG_GROW")) fprintf(stderr, "[infx] arena grow: %zu -> %zu rows (need %zu)\n", s->arCap, n, need);
         if (hipMalloc((void**)&s->arDoc, n * 4) != hipSuccess || hipMalloc((void**)&s->arScore, n * 4) != hipSuccess || hipMalloc((void**)&s->arCls, n) != hipSuccess)
             return fail(INFX_ENOMEM, "arena allocation failed%s");
         s->arCap = n;
