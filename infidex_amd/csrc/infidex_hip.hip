@@ -77,6 +77,8 @@ struct infx_index {
     int rank = 0, nranks = 1;
     ncclComm_t comm = nullptr;         // infx_set_shard_comm
     struct DevLookup* lk = nullptr;    // dictionaries / term trie of the device-side planning lookups (lookup.hip.inc); owned, freed by infx_destroy
+    // Turnstile of the full-width phase (k_accumulate .. k_select) between the streams of an index: see infx_search_fused
+    std::mutex turnMu; hipEvent_t turnEvent = nullptr;
     bool haveDict = false, haveTrie = false;
 };
 
@@ -256,6 +258,7 @@ struct infx_stream {
     // streaming kernels of the other batches in flight they came back after 10-15 ms (measured: plan_ms 14.9 per batch of which ~2 ms host work).  They
     // run on a stream of their own with the highest priority the device offers, so their few hundred waves are placed as soon as any CU has room.
     hipStream_t stPlan = nullptr, stMain = nullptr; hipEvent_t evPlan = nullptr;
+    hipEvent_t evTurn = nullptr;                                   // end of this stream's k_select: what the next batch's k_accumulate (another stream) waits for
     hipStream_t stAux = nullptr; hipEvent_t evJoin = nullptr;      // the replay's two k_ex_chunk launches run side by side (both are tail-bound: one wave per chunk)
     hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1, evX0, evX1, evSync;
     hipEvent_t evXa, evXb, evXc; bool timedReplayParts = false; float msReplayParts[4] = {0, 0, 0, 0};      // inside the replay: after k_ex_scan, after both k_ex_chunk launches, after k_ex_heap
@@ -1003,6 +1006,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
         if (!noAux && hipStreamCreateWithFlags(&s->stAux, hipStreamNonBlocking) == hipSuccess) HIPCHK(hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming));
         else { (void)hipGetLastError(); s->stAux = nullptr; }
     }
+    HIPCHK(hipEventCreateWithFlags(&s->evTurn, hipEventDisableTiming));
     hipEvent_t* ev[] = {&s->evA0, &s->evA1, &s->evS0, &s->evS1, &s->evC0, &s->evC1, &s->evP0, &s->evP1, &s->evF0, &s->evF1, &s->evX0, &s->evX1, &s->evXa, &s->evXb, &s->evXc};
     for (auto e : ev) HIPCHK(hipEventCreate(e));
     HIPCHK(hipEventCreateWithFlags(&s->evSync, hipEventBlockingSync | hipEventDisableTiming));
@@ -1031,6 +1035,8 @@ void infx_stream_destroy(infx_stream* s) {
     hipEventDestroy(s->evSync);
     if (s->evPlan) hipEventDestroy(s->evPlan);
     if (s->evJoin) hipEventDestroy(s->evJoin);
+    { std::lock_guard<std::mutex> lk(s->ix->turnMu); if (s->ix->turnEvent == s->evTurn) s->ix->turnEvent = nullptr; }
+    if (s->evTurn) hipEventDestroy(s->evTurn);
     if (s->stAux) { hipStreamSynchronize(s->stAux); hipStreamDestroy(s->stAux); }
     if (s->stPlan) { hipStreamSynchronize(s->stPlan); hipStreamDestroy(s->stPlan); }
     if (s->st) hipStreamDestroy(s->st);
@@ -1457,7 +1463,7 @@ static int32_t fused_check_queries(infx_index* ix, uint32_t nd, uint32_t nq, con
 }
 
 // k_rules (from the class histogram in s->dCounts) + k_select -> s->dHits / s->dHitCount (stride = depth)
-static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, bool shardNext = false) {
+static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, bool shardNext = false, bool markTurn = false) {
     infx_index* ix = s->ix;
     GROW(s->dRules, s->capRules, std::max<size_t>(1, nd) * sizeof(SelRule));
     GROW(s->dHits, s->capHits, std::max<size_t>(1, (size_t)nd) * depth * sizeof(infx_hit));
@@ -1474,8 +1480,10 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, 
         if (shardNext) GROW(s->dNext, s->capNext, (size_t)nd * 4);       // document shards: no local flags — the cut is global (k_gflag)
         k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr,
                                                 shardNext ? (float*)s->dNext : nullptr);
+        if (markTurn) { HIPCHK(hipEventRecord(s->evTurn, s->st)); markTurn = false; }      // the wide phase of this batch ends here
         if (exact) { int32_t rc_ = enqueue_exact(s, nd, depth); if (rc_) return rc_; }
     }
+    if (markTurn) HIPCHK(hipEventRecord(s->evTurn, s->st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evS1, s->st));
     s->timedSel = true;
@@ -1658,9 +1666,20 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
     for (uint32_t i = 0; i < nd; i++) if (q[i].depth != depth) return fail(INFX_EINVAL, "all queries of a fused batch share one depth%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
-    if (nd) { int32_t rc_ = acc_enqueue(s, nd, q, nterms, terms, 0, nullptr); if (rc_) return rc_; }
-    else { HIPCHK(hipEventRecord(s->evA0, s->st)); HIPCHK(hipEventRecord(s->evA1, s->st)); }
-    { int32_t rc_ = fused_enqueue_select(s, nd, depth); if (rc_) return rc_; }
+    // Turnstile.  k_accumulate and k_select fill the GPU on their own; the replay, candidate assembly and Stage 2 behind them are narrow.  Sessions that
+    // submit together run their wide kernels against each other and then sit in their narrow phases together — convoys that leave the GPU half empty (the
+    // bench timeline showed three batches finishing within a millisecond of each other, then nothing wide to run).  Each batch's k_accumulate therefore waits
+    // (stream-side, no host wait) for the k_select of the batch submitted before it on this index: wide phases queue up one behind the other, each batch's
+    // narrow tail overlaps the next batch's wide phase.  INFX_TURNSTILE=0 switches it off.
+    static const bool turnstile = [] { const char* e = getenv("INFX_TURNSTILE"); return !(e && e[0] == '0'); }();
+    {
+        std::unique_lock<std::mutex> turn(ix->turnMu, std::defer_lock);
+        if (turnstile) { turn.lock(); if (ix->turnEvent && ix->turnEvent != s->evTurn) HIPCHK(hipStreamWaitEvent(s->st, ix->turnEvent, 0)); }
+        if (nd) { int32_t rc_ = acc_enqueue(s, nd, q, nterms, terms, 0, nullptr); if (rc_) return rc_; }
+        else { HIPCHK(hipEventRecord(s->evA0, s->st)); HIPCHK(hipEventRecord(s->evA1, s->st)); }
+        { int32_t rc_ = fused_enqueue_select(s, nd, depth, false, turnstile); if (rc_) return rc_; }
+        if (turnstile) ix->turnEvent = s->evTurn;
+    }
     { int32_t rc_ = fused_enqueue_prep_stage2(s, 1, nd, (const infx_hit*)s->dHits, (const uint32_t*)s->dHitCount, nq, fq, cq, nlists, lists, owned_n, owned, depth, want_debug); if (rc_) return rc_; }
     { int32_t rc_ = fused_enqueue_finalize(s, nq, depth, max_results, out_ties != nullptr); if (rc_) return rc_; }
     uint32_t ovf = 0, err = 0; std::vector<unsigned long long> qbytes(nd); std::vector<SelRule> rules(nd); std::vector<FusedMeta> metas(nq);
