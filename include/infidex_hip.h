@@ -291,6 +291,13 @@ int32_t infx_upload_term_trie(infx_index* idx, uint32_t n_nodes, const uint32_t*
  * (the reference switches to another walk, FstIndex.cs:362-440) — in both cases nothing was written for w and the caller expands it on the host. */
 int32_t infx_ld1_expand(infx_stream* s, uint32_t nwords, const uint32_t* word_offs /* n+1 */, const uint16_t* chars, uint32_t cap,
                         int32_t* members_out /* nwords x cap */, uint32_t* counts_out, uint32_t* status_out);
+/* infx_union_build with the expansion fused in: union v takes its members from members[member_offs[v] .. member_offs[v+1]) when word_of[v] < 0, or from the LD1
+ * expansion of word word_of[v] (each word at most once; its member range must be empty).  k_ld1 closes the word unions' member ranges on the device and the union
+ * kernels follow on the same stream: ONE wait for the device per batch (the counts) instead of two.  A word the kernel hands back (status != 0) yields an empty
+ * union: expand it on the host and build again.  The expansions come back as from infx_ld1_expand. */
+int32_t infx_union_build_ld1(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, const int32_t* word_of /* nv */,
+                             uint32_t nwords, const uint32_t* word_offs /* n+1 */, const uint16_t* chars, uint32_t cap,
+                             uint32_t* counts_out /* nv */, int32_t* ld1_members_out /* nwords x cap */, uint32_t* ld1_counts_out, uint32_t* ld1_status_out);
 /* WordMatcher lists of ONE coverage query as the device produces them (parity tests): lists_out[INFX_MAX_WM_LISTS], *nlists_out of them; src 2 offsets
  * index owned_out (owned_cap ints, >= 4096 per word of the query). */
 int32_t infx_wm_lookup_debug(infx_stream* s, const infx_cov_query* cq, infx_wm_list* lists_out, uint32_t* nlists_out, int32_t* owned_out, uint64_t owned_cap);

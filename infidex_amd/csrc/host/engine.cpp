@@ -139,14 +139,17 @@ struct infx_engine {
     std::vector<uint8_t> deleted;     // Document.Deleted per global internal id; empty = nothing deleted
     std::atomic<long long> ld1OnHost{0}, ld1OnDevice{0}, wmOnHost{0}, wmOnDevice{0};      // where the planning lookups ran (introspection)
     bool devLookups = false;          // WordMatcher dictionaries + term trie uploaded: the LD1 / WordMatcher lookups of planning can run on the GPU (f3)
-    // Where a batch's lookups run when both sides can do them (same results either way, tests/test_gpu_lookups.py): 2 = always the device
-    // (INFX_DEVICE_LOOKUPS=1), 0 = by cost — the host's dictionaries answer in ~21 us per unknown word and ~7 us per WordMatcher word of one core, the device
-    // kernels cost a fraction of a millisecond of GPU time per batch and one more wait for the device.  A host with cores to spare (one GPU per 16 CPUs, two
-    // words per query) plans faster itself (measured at 10 M documents: 73.8 k against 72.0 k queries/s); three fuzzy words per query saturate it (config 3:
-    // 36 k against 65 k), and so do eight ranks sharing one CPU quota.  The device takes a batch whose estimated host lookup time exceeds a quarter of the
-    // planner threads' time in one typical batch interval (10 ms).
-    int lookupPolicy = 0;
-    bool lookups_on_device(double estThreadMs) const { return devLookups && (lookupPolicy == 2 || estThreadMs > 2.5 * (double)std::max(1, threads)); }
+    // Both sides can answer a batch's lookups with identical results (tests/test_gpu_lookups.py).
+    // WordMatcher: always the device once the dictionaries are uploaded — k_wm rides inside the batch's pipeline (0.12 ms, no extra wait), while the host's cost
+    // depends on the sizes of the affix ranges (config 3: 37 ms of 16 threads per batch; a word-count model sent it to the host and halved the rate).
+    // LD1 expansion: by cost.  The host walk is predictable (~21 us of one core per unknown word, spread over the planner threads); k_ld1 is one latency-bound wave
+    // per word whose result the host WAITS for, and behind five other batches' streaming kernels that wait is ~15 ms (0.2 ms on an idle GPU): with cores to spare
+    // the host is faster (10 M documents, 16 CPUs: 74.8 k against 68.7 k queries/s); the device takes the batch when the estimated host time exceeds a quarter of
+    // the planner threads' time in a 10-ms batch interval — two threads per rank on an 8-GPU node, or thousands of unknown words.  INFX_DEVICE_LOOKUPS=1 pins the
+    // device (the GPU test suite does), INFX_HOST_LOOKUPS=1 keeps everything on the host (no upload).
+    bool ld1Pinned = false;
+    bool ld1_on_device(double estThreadMs) const { return devLookups && (ld1Pinned || estThreadMs > 2.5 * (double)std::max(1, threads)); }
+    bool lookups_on_device(double) const { return devLookups; }
     int threads = 1;
     int buildThreads = 0;             // > 0: threads of the index build only (infx_engine_set_build_threads)
     infx_session* def = nullptr;      // default session (single-caller API)
@@ -255,7 +258,7 @@ static int32_t upload_lookups(infx_engine* e) {
         if (rc) return rc;
     }
     e->devLookups = true;
-    { const char* d = getenv("INFX_DEVICE_LOOKUPS"); e->lookupPolicy = (d && d[0] == '1') ? 2 : 0; }
+    { const char* d = getenv("INFX_DEVICE_LOOKUPS"); e->ld1Pinned = d && d[0] == '1'; }
     return INFX_OK;
 }
 
@@ -333,17 +336,27 @@ static int32_t key_to_id(infx_engine* e, int64_t key) {
 
 // FstIndex.MatchWithinEditDistance1 for the distinct unknown words of a batch that the expansion cache does not hold: one infx_ld1_expand call; the few
 // words the kernel hands back (work lists outgrown, longer than 64 characters) are expanded by the host walk.  Results enter the LRU cache as before.
-static int32_t expand_pending(infx_engine* e, infx_session* S, std::vector<QueryPlan>& plans) {
+// Words of the batch that wait for the device expansion fused into the union build (infx_union_build_ld1): placeholders until the members are back
+struct DevLd1 { std::vector<ustr> words; std::vector<std::shared_ptr<FuzzyUnion>> fz; };
+static int32_t expand_pending(infx_engine* e, infx_session* S, std::vector<QueryPlan>& plans, DevLd1* dev) {
     const HostIndex& ix = e->ix;
     std::vector<const ustr*> words; std::unordered_map<std::u16string, uint32_t> idx;
     for (auto& P : plans) for (auto& r : P.rawTok) if (r.pending && idx.emplace(r.text, (uint32_t)words.size()).second) words.push_back(&r.text);
     if (words.empty()) return INFX_OK;
     const uint32_t nw = (uint32_t)words.size(), cap = 1024;
+    static const bool fusedOff = [] { const char* v = getenv("INFX_LD1_FUSED"); return v && v[0] == '0'; }();
+    if (dev && !fusedOff && e->ld1_on_device(0.021 * (double)nw)) {
+        // the device expands these words inside the union build (one wait for the device instead of two): every occurrence gets the word's placeholder union
+        dev->words.resize(nw); dev->fz.resize(nw);
+        for (uint32_t i = 0; i < nw; i++) { dev->words[i] = *words[i]; dev->fz[i] = std::make_shared<FuzzyUnion>(); }
+        for (auto& P : plans) for (auto& r : P.rawTok) if (r.pending) { r.fz = dev->fz[idx.at(r.text)]; r.pending = false; }
+        return INFX_OK;
+    }
     std::vector<std::shared_ptr<FuzzyUnion>> made(nw);
     std::vector<uint32_t> offs(nw + 1, 0), counts(nw, 0), status(nw, 2); std::vector<u16> chars; std::vector<int32_t> members((size_t)nw * cap);
     for (uint32_t i = 0; i < nw; i++) { if (words[i]->size() <= 64) chars.insert(chars.end(), words[i]->begin(), words[i]->end()); offs[i + 1] = (uint32_t)chars.size(); }     // longer words: empty -> status 2
     auto t0 = std::chrono::steady_clock::now();
-    if (e->lookups_on_device(0.021 * (double)nw)) {
+    if (e->ld1_on_device(0.021 * (double)nw)) {
         int32_t rc;
         { PlanGatePause pause; rc = infx_ld1_expand(S->stream, nw, offs.data(), (const uint16_t*)chars.data(), cap, members.data(), counts.data(), status.data()); }
         if (rc) { g_eerr = infx_last_error(); return rc; }
@@ -378,7 +391,8 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
     parallel_dyn(nq, threads, devLd1 ? 8 : 1, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; i++) plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i], false, devLd1);
     });
-    if (devLd1) { int32_t rc = expand_pending(e, S, plans); if (rc) return rc; }
+    DevLd1 dl;
+    if (devLd1) { int32_t rc = expand_pending(e, S, plans, &dl); if (rc) return rc; }
     B.tTok = now_ms() - B.t0;
     {   // every fuzzy union this batch uses is materialised on the device (this shard's slice); |union| = its df (sharded:
         // summed over the shards by the caller)
@@ -398,7 +412,38 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
         for (size_t v = 0; v < B.pending.size(); v++) { mm.insert(mm.end(), B.pending[v]->members.begin(), B.pending[v]->members.end()); mo[v + 1] = (uint32_t)mm.size(); }
         const double tu0 = now_ms();
         int32_t rc;
-        { PlanGatePause pause; rc = infx_union_build(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), B.pendingCounts.data()); }
+        if (dl.words.empty()) { PlanGatePause pause; rc = infx_union_build(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), B.pendingCounts.data()); }
+        else {
+            // k_ld1 for the placeholders' words, k_union for every union of the batch, one wait (infx_union_build_ld1)
+            const uint32_t nw = (uint32_t)dl.words.size(), cap = 1024;
+            std::unordered_map<const FuzzyUnion*, int32_t> wordOfFz; for (uint32_t w = 0; w < nw; w++) wordOfFz.emplace(dl.fz[w].get(), (int32_t)w);
+            std::vector<int32_t> wordOf(B.pending.size(), -1);
+            for (size_t v = 0; v < B.pending.size(); v++) { auto it = wordOfFz.find(B.pending[v].get()); if (it != wordOfFz.end()) wordOf[v] = it->second; }
+            std::vector<uint32_t> wo(nw + 1, 0), lc(nw, 0), ls(nw, 2); std::vector<u16> wc; std::vector<int32_t> lm((size_t)nw * cap);
+            for (uint32_t w = 0; w < nw; w++) { if (dl.words[w].size() <= 64) wc.insert(wc.end(), dl.words[w].begin(), dl.words[w].end()); wo[w + 1] = (uint32_t)wc.size(); }      // longer words: empty -> status 2
+            { PlanGatePause pause; rc = infx_union_build_ld1(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), wordOf.data(), nw, wo.data(), (const uint16_t*)wc.data(), cap,
+                                                            B.pendingCounts.data(), lm.data(), lc.data(), ls.data()); }
+            if (rc) { g_eerr = infx_last_error(); return rc; }
+            B.tLd1Dev = now_ms() - tu0;
+            std::vector<uint32_t> onHost;
+            for (uint32_t w = 0; w < nw; w++) {
+                if (ls[w] == 0) { auto u = union_of_matches(ix, lm.data() + (size_t)w * cap, std::min(lc[w], cap)); dl.fz[w]->members.swap(u->members); }
+                else onHost.push_back(w);
+            }
+            e->ld1OnDevice += (long long)(nw - onHost.size()); e->ld1OnHost += (long long)onHost.size(); e->fuzzy.fuzzyCalls += nw;
+            if (!onHost.empty()) {
+                // the few words the kernel handed back: host walk, then the unions once more with every member list known
+                parallel_dyn((int64_t)onHost.size(), threads, 1, [&](int64_t b, int64_t en, int) {
+                    std::vector<int> m;
+                    for (int64_t k = b; k < en; k++) { const uint32_t w = onHost[k]; match_ld1(ix, dl.words[w], m, (int)cap); auto u = union_of_matches(ix, m.data(), m.size()); dl.fz[w]->members.swap(u->members); }
+                });
+                mm.clear();
+                for (size_t v = 0; v < B.pending.size(); v++) { mm.insert(mm.end(), B.pending[v]->members.begin(), B.pending[v]->members.end()); mo[v + 1] = (uint32_t)mm.size(); }
+                { PlanGatePause pause; rc = infx_union_build(S->stream, (uint32_t)B.pending.size(), mo.data(), mm.data(), B.pendingCounts.data()); }
+                if (rc) { g_eerr = infx_last_error(); return rc; }
+            }
+            for (uint32_t w = 0; w < nw; w++) e->fuzzy.put(dl.words[w], dl.fz[w]);      // into the expansion cache (LRU 1000, as the reference's)
+        }
         if (rc) { g_eerr = infx_last_error(); return rc; }
         B.tUnionDev = now_ms() - tu0;
     }

@@ -462,20 +462,20 @@ struct PlanStream {
 #define DOWN(dst, src, n) do { int32_t rc_ = down(s, (dst), (src), (n)); if (rc_) return rc_; } while (0)
 #define SYNC() do { int32_t rc_ = stream_sync(s); if (rc_) return rc_; } while (0)
 
-template <int R> static void launch_union(infx_stream* s, uint32_t nv, const uint32_t* dOffs, const int32_t* dMembers, uint32_t* dRangeCount,
+template <int R> static void launch_union(infx_stream* s, uint32_t nv, const uint32_t* dBeg, const uint32_t* dEnd, const int32_t* dMembers, uint32_t* dRangeCount,
                                             const unsigned long long* dBase, int32_t* outDocs) {
     uint64_t blocks = (uint64_t)nv * s->ix->d.nRanges;
-    k_union<R><<<dim3((unsigned)blocks), dim3(WAVE), 0, s->st>>>(s->ix->d, dOffs, dMembers, nv, dRangeCount, dBase, outDocs);
+    k_union<R><<<dim3((unsigned)blocks), dim3(WAVE), 0, s->st>>>(s->ix->d, dBeg, dEnd, dMembers, nv, dRangeCount, dBase, outDocs);
 }
-static void launch_union_any(infx_stream* s, uint32_t nv, const uint32_t* dOffs, const int32_t* dMembers, uint32_t* dRangeCount,
+static void launch_union_any(infx_stream* s, uint32_t nv, const uint32_t* dBeg, const uint32_t* dEnd, const int32_t* dMembers, uint32_t* dRangeCount,
                              const unsigned long long* dBase, int32_t* outDocs) {
     switch (s->ix->d.R) {
-        case 512: launch_union<512>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
-        case 1024: launch_union<1024>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
-        case 2048: launch_union<2048>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
-        case 4096: launch_union<4096>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
-        case 8192: launch_union<8192>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
-        default: launch_union<16384>(s, nv, dOffs, dMembers, dRangeCount, dBase, outDocs); break;
+        case 512: launch_union<512>(s, nv, dBeg, dEnd, dMembers, dRangeCount, dBase, outDocs); break;
+        case 1024: launch_union<1024>(s, nv, dBeg, dEnd, dMembers, dRangeCount, dBase, outDocs); break;
+        case 2048: launch_union<2048>(s, nv, dBeg, dEnd, dMembers, dRangeCount, dBase, outDocs); break;
+        case 4096: launch_union<4096>(s, nv, dBeg, dEnd, dMembers, dRangeCount, dBase, outDocs); break;
+        case 8192: launch_union<8192>(s, nv, dBeg, dEnd, dMembers, dRangeCount, dBase, outDocs); break;
+        default: launch_union<16384>(s, nv, dBeg, dEnd, dMembers, dRangeCount, dBase, outDocs); break;
     }
 }
 // exact replay of the reference's Stage-1 order effects (k_exact1) — on unless INFX_EXACT=0
@@ -1409,7 +1409,7 @@ int32_t infx_ld1_expand(infx_stream* s, uint32_t nwords, const uint32_t* word_of
     UP(s->dLWordOff, word_offs, ((size_t)nwords + 1) * 4);
     UP(s->dLChars, chars, nch * 2);
     uint32_t* dCnt = (uint32_t*)s->dLCount; uint32_t* dSt = dCnt + nwords;
-    k_ld1<<<nwords, WAVE, 0, s->st>>>(*ix->lk, (const uint32_t*)s->dLWordOff, (const uint16_t*)s->dLChars, nwords, cap, (int32_t*)s->dLMembers, dCnt, dSt);
+    k_ld1<<<nwords, WAVE, 0, s->st>>>(*ix->lk, (const uint32_t*)s->dLWordOff, (const uint16_t*)s->dLChars, nwords, cap, (int32_t*)s->dLMembers, dCnt, dSt, nullptr, nullptr, 0u);
     HIPCHK(hipGetLastError());
     DOWN(counts_out, dCnt, (size_t)nwords * 4);
     DOWN(status_out, dSt, (size_t)nwords * 4);
@@ -1944,12 +1944,14 @@ int32_t infx_last_timings(infx_stream* s, float* a, float* b, float* c) {
     if (a) *a = s->msAcc; if (b) *b = s->msSel; if (c) *c = s->msCov;
     return INFX_OK;
 }
-int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out) {
-    if (!s || (nv && (!member_offs || !counts_out || (member_offs[nv] && !members)))) return fail(INFX_EINVAL, "null argument%s");
+static int32_t union_build_impl(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out,
+                                const int32_t* word_of, uint32_t nwords, const uint32_t* word_offs, const uint16_t* chars, uint32_t cap,
+                                int32_t* ld1_members_out, uint32_t* ld1_counts_out, uint32_t* ld1_status_out) {
     s->unionCount.clear(); s->unionBase.assign(1, 0);
     if (nv == 0) return INFX_OK;
     infx_index* ix = s->ix;
     if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
+    if (nwords && !ix->haveTrie) return fail(INFX_EINVAL, "infx_upload_term_trie has not been called%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     PlanStream plan(s);
@@ -1957,17 +1959,43 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     if ((uint64_t)nv * nR > 0x7FFFFFFFull) return fail(INFX_ECAPACITY, "nv * nRanges exceeds the grid limit%s");
     const uint32_t nm = member_offs[nv];
     for (uint32_t i = 0; i < nm; i++) if (members[i] < 0 || members[i] >= ix->d.T) return fail(INFX_EINVAL, "member term id out of range%s");
-    GROW(s->dUOffs, s->capUOffs, ((size_t)nv + 1) * 4);
-    GROW(s->dUMem, s->capUMem, std::max<size_t>(1, nm) * 4);
+    if ((uint64_t)nm + (uint64_t)nwords * cap > 0xFFFFFFF0ull) return fail(INFX_ECAPACITY, "too many union members in one batch%s");
+    // member ranges: CSR for the unions the caller listed, the word's slot of the tail (closed by k_ld1) for the others
+    std::vector<uint32_t> be((size_t)nv * 2); std::vector<int32_t> uow(nwords, -1);
+    for (uint32_t v = 0; v < nv; v++) {
+        const int32_t w = word_of ? word_of[v] : -1;
+        if (w >= 0) { if ((uint32_t)w >= nwords || uow[w] >= 0 || member_offs[v + 1] != member_offs[v]) return fail(INFX_EINVAL, "bad word reference of a union%s"); uow[w] = (int32_t)v; be[v] = nm + (uint32_t)w * cap; be[nv + v] = be[v]; }
+        else { be[v] = member_offs[v]; be[nv + v] = member_offs[v + 1]; }
+    }
+    GROW(s->dUOffs, s->capUOffs, ((size_t)nv * 2 + 2) * 4);
+    GROW(s->dUMem, s->capUMem, std::max<size_t>(1, (size_t)nm + (size_t)nwords * cap) * 4);
     GROW(s->dUCnt, s->capUCnt, (size_t)nv * 4);
     GROW(s->dURange, s->capURange, (size_t)nv * (nR + 1) * 4);
     GROW(s->dUBase, s->capUBase, ((size_t)nv + 1) * 8);
-    UP(s->dUOffs, member_offs, ((size_t)nv + 1) * 4);
+    UP(s->dUOffs, be.data(), be.size() * 4);
     UP(s->dUMem, members, (size_t)nm * 4);
-    launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, nullptr, nullptr);
+    uint32_t* dBeg = (uint32_t*)s->dUOffs; uint32_t* dEnd = dBeg + nv;
+    uint32_t *dCnt = nullptr, *dSt = nullptr;
+    if (nwords) {
+        const size_t nch = word_offs[nwords];
+        GROW(s->dLWordOff, s->capLWordOff, ((size_t)nwords * 2 + 2) * 4);
+        GROW(s->dLChars, s->capLChars, std::max<size_t>(1, nch) * 2);
+        GROW(s->dLCount, s->capLCount, (size_t)nwords * 8);
+        UP(s->dLWordOff, word_offs, ((size_t)nwords + 1) * 4);
+        UP((uint32_t*)s->dLWordOff + nwords + 1, uow.data(), (size_t)nwords * 4);
+        UP(s->dLChars, chars, nch * 2);
+        dCnt = (uint32_t*)s->dLCount; dSt = dCnt + nwords;
+        k_ld1<<<nwords, WAVE, 0, s->st>>>(*ix->lk, (const uint32_t*)s->dLWordOff, (const uint16_t*)s->dLChars, nwords, cap, (int32_t*)s->dUMem + nm, dCnt, dSt,
+                                          dEnd, (const int32_t*)((uint32_t*)s->dLWordOff + nwords + 1), nm);
+        HIPCHK(hipGetLastError());
+    }
+    launch_union_any(s, nv, dBeg, dEnd, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, nullptr, nullptr);
     k_union_scan<<<nv, 256, 0, s->st>>>((uint32_t*)s->dURange, nR, (uint32_t*)s->dUCnt);
     HIPCHK(hipGetLastError());
     DOWN(counts_out, s->dUCnt, (size_t)nv * 4);
+    // the expansions travel back with the counts (nwords x cap ids: a few MB at most) — one wait; fetching only the filled part of each row would need the counts
+    // first, i.e. a second wait, and that one would sit behind the write pass below
+    if (nwords) { DOWN(ld1_counts_out, dCnt, (size_t)nwords * 4); DOWN(ld1_status_out, dSt, (size_t)nwords * 4); DOWN(ld1_members_out, (const int32_t*)s->dUMem + nm, (size_t)nwords * cap * 4); }
     SYNC();
     s->unionCount.assign(counts_out, counts_out + nv);
     s->unionBase.assign((size_t)nv + 1, 0);
@@ -1975,9 +2003,20 @@ int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_off
     GROW(s->dUDocs, s->capUDocs, ((size_t)s->unionBase[nv] + 4) * 4);
     HIPCHK(hipMemsetAsync(s->dUDocs, 0x7F, ((size_t)s->unionBase[nv] + 4) * 4, s->st));
     UP(s->dUBase, s->unionBase.data(), ((size_t)nv + 1) * 8);
-    launch_union_any(s, nv, (const uint32_t*)s->dUOffs, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, (const unsigned long long*)s->dUBase, (int32_t*)s->dUDocs);
+    launch_union_any(s, nv, dBeg, dEnd, (const int32_t*)s->dUMem, (uint32_t*)s->dURange, (const unsigned long long*)s->dUBase, (int32_t*)s->dUDocs);
     HIPCHK(hipGetLastError());
     return plan.leave();     // the write pass stays queued (planning stream); the main stream — infx_stage1_accumulate — is ordered behind it
+}
+int32_t infx_union_build(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, uint32_t* counts_out) {
+    if (!s || (nv && (!member_offs || !counts_out || (member_offs[nv] && !members)))) return fail(INFX_EINVAL, "null argument%s");
+    return union_build_impl(s, nv, member_offs, members, counts_out, nullptr, 0, nullptr, nullptr, 1, nullptr, nullptr, nullptr);
+}
+int32_t infx_union_build_ld1(infx_stream* s, uint32_t nv, const uint32_t* member_offs, const int32_t* members, const int32_t* word_of,
+                             uint32_t nwords, const uint32_t* word_offs, const uint16_t* chars, uint32_t cap,
+                             uint32_t* counts_out, int32_t* ld1_members_out, uint32_t* ld1_counts_out, uint32_t* ld1_status_out) {
+    if (!s || (nv && (!member_offs || !counts_out || (member_offs[nv] && !members))) || (nwords && (!word_of || !word_offs || !ld1_members_out || !ld1_counts_out || !ld1_status_out || (word_offs[nwords] && !chars))) || cap == 0)
+        return fail(INFX_EINVAL, "null argument%s");
+    return union_build_impl(s, nv, member_offs, members, counts_out, nwords ? word_of : nullptr, nwords, word_offs, chars, cap, ld1_members_out, ld1_counts_out, ld1_status_out);
 }
 int32_t infx_last_replay_stats(infx_stream* s, float* ms, uint32_t* why3) {
     if (!s) return fail(INFX_EINVAL, "null argument%s");

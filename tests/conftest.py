@@ -7,9 +7,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The planning lookups (LD1 expansion, WordMatcher) run on the device or on the host, whichever is estimated cheaper for the batch (csrc/host/engine.cpp,
-# lookups_on_device) — with the small batches of the tests that would almost always be the host.  The GPU suite pins them to the DEVICE so that every parity
-# test exercises k_ld1 / k_wm; the host side is covered by the CPU suite and by the device-vs-host A/B test (which sets the variables itself).
+# The LD1 expansion of a batch's unknown words runs on the device or on the host, whichever is estimated cheaper (csrc/host/engine.cpp, ld1_on_device) — with the
+# small batches of the tests that would be the host.  The GPU suite pins it to the DEVICE so that every parity test exercises k_ld1 (k_wm always runs on the device);
+# the host walk is covered by the CPU suite and by the device-vs-host A/B test.
 os.environ.setdefault("INFX_DEVICE_LOOKUPS", "1")
 
 

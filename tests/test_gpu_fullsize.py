@@ -2,7 +2,8 @@
    config 2: 100 000 single-field documents, 2-word exact queries, top-10 — a 1000-query batch, the first 300 queries checked against the oracle;
    config 3: 1 000 000 two-field documents (title High, description Low), 3-word queries with one fuzzed word, top-20 — a 1000-query batch, 100 checked.
 Identical final DocumentId sets, scores within the 2^-6 quantisation step, order flips only between quantisation-step neighbours
-(tests/parity_classify.py).  Planning runs with the dictionaries on the device (the default), so these are also full-size runs of k_wm / k_ld1."""
+(tests/parity_classify.py).  Planning runs with the dictionaries on the device (tests/conftest.py pins the LD1 expansion there too), so these are also full-size
+runs of k_wm / k_ld1."""
 import numpy as np
 import pytest
 

@@ -130,7 +130,7 @@ np.savez(sys.argv[1], k=k, sc=sc.view(np.uint32), t=t, c=c, f=f, stats=np.array(
 '''
     res = []
     for host in ("0", "1"):
-        env = dict(os.environ); env["INFX_HOST_LOOKUPS"] = host; env["INFX_DEVICE_LOOKUPS"] = "1"      # "0": dictionaries uploaded and every batch sent to them; "1": no upload
+        env = dict(os.environ); env["INFX_HOST_LOOKUPS"] = host; env["INFX_DEVICE_LOOKUPS"] = "1"      # "0": dictionaries uploaded, every lookup on the device; "1": no upload, host
         env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         out = str(tmp_path / f"lk{host}.npz")
         subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=900)
