@@ -1,22 +1,22 @@
 #!/bin/bash
-# Round-4 profile on the GPU box: bench lines (driver's 20-step form, 256 steps with the CPU baseline, configs 2 / 3 / 5, the sharded path on one rank),
-# kernel trace, PMC passes for k_accumulate (each its own run; --pmc never together with trace flags).  Output: gpurun_out/prof_r04/
+# Round-4 profile on the GPU box: bench lines (driver's 20-step form with the CPU baseline, 256 steps, configs 2 / 3 / 5, the sharded path on one rank), kernel trace,
+# PMC passes for k_accumulate (each its own run; --pmc never together with trace flags).  Output: gpurun_out/prof_r04/
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r04; rm -rf $O; mkdir -p $O
 python $R/bench.py --steps 20 --warmup 5 > $O/bench_20steps.json 2> $O/bench_20steps.err
 python $R/bench.py --no-cpu-baseline > $O/bench_256steps.json 2> $O/bench_256steps.err
-for c in 2 3 5; do python $R/bench.py --config $c --steps 60 --warmup 5 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; done
+python $R/bench.py --config 2 --steps 60 --warmup 5 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
+python $R/bench.py --config 3 --steps 60 --warmup 5 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
+python $R/bench.py --config 5 --steps 60 --warmup 5 --no-cpu-baseline > $O/bench_cfg5.json 2> $O/bench_cfg5.err
 INFX_FORCE_SHARDED=1 python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline > $O/bench_sharded_w1.json 2> $O/bench_sharded_w1.err
 B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --sessions 1"
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- $B > $O/kt.json 2> $O/kt.err
 find $O/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv; rm -rf $O/kt
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- $B > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum -d $O/pmc_tcc -o p --output-format csv -- $B > $O/pmc_tcc.json 2> $O/pmc_tcc.err
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY -d $O/pmc_sq -o p --output-format csv -- $B > $O/pmc_sq.json 2> $O/pmc_sq.err
-timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_sq2 -o p --output-format csv -- $B > $O/pmc_sq2.json 2> $O/pmc_sq2.err
-for d in pmc_fetch pmc_tcc pmc_sq pmc_sq2; do python $R/tools/pmc_summary.py $O/$d "k_accumulate<8192, 2>" > $O/$d.txt 2>&1; python $R/tools/pmc_summary.py $O/$d > $O/${d}_all.txt 2>&1; rm -rf $O/$d; done
+for d in pmc_fetch pmc_sq; do python $R/tools/pmc_summary.py $O/$d "k_accumulate<8192, 2>" > $O/$d.txt 2>&1; rm -rf $O/$d; done
 python -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_sha16())" > $O/kernel_sha16.txt
-cat $O/pmc_fetch.txt $O/pmc_tcc.txt $O/pmc_sq.txt $O/pmc_sq2.txt; head -22 $O/kernel_stats.csv | cut -c1-150
+cat $O/pmc_fetch.txt $O/pmc_sq.txt; head -16 $O/kernel_stats.csv | cut -c1-50
 for f in bench_20steps bench_256steps bench_cfg2 bench_cfg3 bench_cfg5 bench_sharded_w1; do python - $O/$f.json <<'PY'
 import json,sys
 try:
