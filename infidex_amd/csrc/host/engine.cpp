@@ -218,6 +218,7 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
     if (!e || n < 0 || (n && (!arena || !offs)) || field_count < 1 || !field_weights) return efail(INFX_EINVAL, "bad arguments");
     if (e->indexed) return efail(INFX_EINVAL, "this engine instance is already indexed (re-indexing: create a new engine)");
     if (n > 0x7FFFFFF0ll) return efail(INFX_EINVAL, "too many documents");
+    for (int64_t i = 0, m = n * field_count; i < m; i++) if (offs[i + 1] < offs[i]) return efail(INFX_EINVAL, "field offsets must be ascending (offs[n * field_count] = the arena's length)");
     DocSource src{n, field_count, field_weights, keys, (const u16*)arena, offs};
     {
         const int planThreads = e->ix.cfg.threads;

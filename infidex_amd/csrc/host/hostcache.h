@@ -3,13 +3,17 @@
 // processes building it at once on the node's shared cores take W times the CPU work.  Instead the node's leader builds it once with every core and
 // writes it here (a file under /dev/shm); the other processes read it back — plain arrays, a couple of seconds — and upload their own shard.
 // The file is a transient hand-off between processes of ONE build on ONE node: raw little-endian arrays behind a header that pins the layout version,
-// the configuration the index was built with and the index fingerprint; a truncated or foreign file is refused.  It is not the reference's INFDX2
-// format (host/infdx2.h reads that).
+// the configuration the index was built with, the index fingerprint and a checksum of the payload; a truncated, foreign or altered file is refused.
+// The writer creates its file exclusively (O_EXCL | O_NOFOLLOW, mode 0600): a link somebody planted at the predictable path of a world-writable
+// directory is not written through.  It is not the reference's INFDX2 format (host/infdx2.h reads that).
 #pragma once
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
+#include <fcntl.h>
+#include <unistd.h>
 #include "index.h"
 
 namespace hostcache {
@@ -17,15 +21,27 @@ using namespace infx;
 static const char MAGIC[8] = {'I', 'N', 'F', 'X', 'H', 'I', 'C', '1'};
 static const char TAIL[8] = {'1', 'C', 'I', 'H', 'X', 'F', 'N', 'I'};
 
+// checksum of the payload: a multiply-xor hash over 8-byte words, chunk by chunk as the arrays stream through (the chunk boundaries are the same for
+// writer and reader: both walk the same ar() sequence)
+struct Sum {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    void add(const void* p, size_t n) {
+        const uint8_t* b = (const uint8_t*)p; uint64_t x = h; size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); x = (x ^ w) * 0xFF51AFD7ED558CCDull; x ^= x >> 29; }
+        uint64_t w = 0; if (i < n) std::memcpy(&w, b + i, n - i);
+        x = (x ^ w ^ ((uint64_t)n << 56)) * 0xC4CEB9FE1A85EC53ull; x ^= x >> 32;
+        h = x;
+    }
+};
 struct Writer {
-    FILE* f; bool ok = true; uint64_t bytes = 0;
-    void raw(const void* p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; bytes += n; }
+    FILE* f; bool ok = true; uint64_t bytes = 0; Sum sum;
+    void raw(const void* p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; bytes += n; sum.add(p, n); }
     template <class T> void pod(T& v) { raw(&v, sizeof(T)); }
     template <class T> void vec(std::vector<T>& v) { uint64_t n = v.size(); pod(n); raw(v.data(), (size_t)n * sizeof(T)); }
 };
 struct Reader {
-    FILE* f; uint64_t left; bool ok = true;      // left: bytes the file still holds (no length field can ask for more)
-    void raw(void* p, size_t n) { if (!ok) return; if (n > left || (n && fread(p, 1, n, f) != n)) { ok = false; return; } left -= n; }
+    FILE* f; uint64_t left; bool ok = true; Sum sum;      // left: bytes the file still holds (no length field can ask for more)
+    void raw(void* p, size_t n) { if (!ok) return; if (n > left || (n && fread(p, 1, n, f) != n)) { ok = false; return; } left -= n; sum.add(p, n); }
     template <class T> void pod(T& v) { raw(&v, sizeof(T)); }
     template <class T> void vec(std::vector<T>& v) { uint64_t n = 0; pod(n); if (!ok || n > left / sizeof(T)) { ok = false; return; } v.resize((size_t)n); raw(v.data(), (size_t)n * sizeof(T)); }
 };
@@ -50,29 +66,35 @@ inline uint64_t config_signature(const HostConfig& c, uint64_t synHash) {
     mix(iv, sizeof(iv)); mix(c.fieldWeights, sizeof(c.fieldWeights)); mix(&synHash, sizeof(synHash));
     return h;
 }
-struct Header { char magic[8]; uint32_t version, keysAreIds; uint64_t configSig, fingerprint, payloadBytes; };
+struct Header { char magic[8]; uint32_t version, keysAreIds; uint64_t configSig, fingerprint, payloadBytes, payloadSum; };
+constexpr uint32_t VERSION = 2;
 
 // returns an empty string on success, else what went wrong
 inline std::string save(const char* path, HostIndex& ix, bool keysAreIds, uint64_t configSig, uint64_t fingerprint) {
     const std::string tmp = std::string(path) + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f) return "cannot create " + tmp;
-    Header h{}; std::memcpy(h.magic, MAGIC, 8); h.version = 1; h.keysAreIds = keysAreIds ? 1u : 0u; h.configSig = configSig; h.fingerprint = fingerprint; h.payloadBytes = 0;
+    unlink(tmp.c_str());                                   // a stale file of a crashed run (unlink does not follow a link)
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return "cannot create " + tmp + " (exclusive creation: " + std::strerror(errno) + ")";
+    FILE* f = fdopen(fd, "wb");
+    if (!f) { close(fd); unlink(tmp.c_str()); return "cannot create " + tmp; }
+    Header h{}; std::memcpy(h.magic, MAGIC, 8); h.version = VERSION; h.keysAreIds = keysAreIds ? 1u : 0u; h.configSig = configSig; h.fingerprint = fingerprint; h.payloadBytes = 0;
     Writer w{f};
     w.raw(&h, sizeof(h));
+    w.sum = Sum{};                                          // the checksum covers the payload only
     ar(w, ix);
-    const uint64_t payload = w.bytes - sizeof(h);
+    const uint64_t payload = w.bytes - sizeof(h), psum = w.sum.h;
     w.raw(TAIL, 8);
     bool ok = w.ok;
-    if (ok && fseek(f, 0, SEEK_SET) == 0) { h.payloadBytes = payload; ok = fwrite(&h, 1, sizeof(h), f) == sizeof(h); } else ok = false;
+    if (ok && fseek(f, 0, SEEK_SET) == 0) { h.payloadBytes = payload; h.payloadSum = psum; ok = fwrite(&h, 1, sizeof(h), f) == sizeof(h); } else ok = false;
     if (fclose(f) != 0) ok = false;
     if (!ok) { remove(tmp.c_str()); return "short write to " + tmp + " (is the file system full?)"; }
     if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return std::string("cannot rename the cache file to ") + path; }
     return "";
 }
 inline std::string load(const char* path, HostIndex& ix, bool& keysAreIds, uint64_t configSig, uint64_t (*fingerprintOf)(const HostIndex&)) {
-    FILE* f = fopen(path, "rb");
-    if (!f) return std::string("cannot open ") + path;
+    const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    FILE* f = fd < 0 ? nullptr : fdopen(fd, "rb");
+    if (!f) { if (fd >= 0) close(fd); return std::string("cannot open ") + path; }
     std::string err;
     const HostConfig keep = ix.cfg;
     do {
@@ -81,13 +103,14 @@ inline std::string load(const char* path, HostIndex& ix, bool& keysAreIds, uint6
         if (size < (long long)(sizeof(Header) + 8) || fseek(f, 0, SEEK_SET) != 0) { err = "file too short for a host-index cache"; break; }
         Header h{};
         if (fread(&h, 1, sizeof(h), f) != sizeof(h) || std::memcmp(h.magic, MAGIC, 8) != 0) { err = "not a host-index cache (magic)"; break; }
-        if (h.version != 1) { err = "host-index cache of another layout version"; break; }
+        if (h.version != VERSION) { err = "host-index cache of another layout version"; break; }
         if (h.configSig != configSig) { err = "host-index cache was built with another configuration (n-gram / stop-term / WordMatcher / synonym settings must match on every rank)"; break; }
         if (h.payloadBytes != (uint64_t)size - sizeof(Header) - 8) { err = "host-index cache is truncated"; break; }
         Reader r{f, h.payloadBytes};
         ar(r, ix);
         char tail[8];
         if (!r.ok || r.left != 0 || fread(tail, 1, 8, f) != 8 || std::memcmp(tail, TAIL, 8) != 0) { err = "host-index cache is corrupt (lengths do not add up)"; break; }
+        if (r.sum.h != h.payloadSum) { err = "host-index cache is corrupt (payload checksum)"; break; }
         if (fingerprintOf(ix) != h.fingerprint) { err = "host-index cache does not match its own fingerprint"; break; }
         // cheap structural checks before anything indexes into the arrays
         const size_t N = (size_t)ix.N, T = ix.terms.K();

@@ -103,25 +103,61 @@ def create_sharded_engine(rank: int, world: int, device: int, **kw) -> SearchEng
     return eng
 
 
+def _job_dir(cache_dir: str, tag: str, create: bool) -> str:
+    """Private directory of one job's hand-off under `cache_dir` (mode 0700, owned by this user, not a link): the path is predictable, the directory
+    is world-writable, so nothing is written through what somebody else may have put there."""
+    d = os.path.join(cache_dir, f"infx_{os.getuid()}_{tag}")
+    if create:
+        try:
+            os.mkdir(d, 0o700)
+        except FileExistsError:
+            pass
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError(f"{d}: not a private directory of this user - refusing to hand the host index over through it")
+    return d
+
+
 def index_flat_per_node(eng: SearchEngine, barrier, local_rank: int, node_cpus: int, keys, arena, offs, field_weights, tag: str, cache_dir: str = "/dev/shm"):
     """One host-index build per NODE instead of one per rank.  The node's leader (local rank 0) indexes the documents with every core of the node and
-    saves the host index under `cache_dir`; the node's other ranks wait (`barrier()`: any barrier over the ranks, e.g. torch.distributed.barrier), read
-    the arrays back and upload their own shard; the leader removes the file after a second barrier.  `tag` must be the same on the ranks of a node and
-    unique per job (e.g. MASTER_PORT).  Every rank ends up with the same host index as if it had called index_flat itself."""
-    path = os.path.join(cache_dir, f"infx_host_index_{tag}.bin")
-    if local_rank == 0:
-        eng.set_build_threads(node_cpus)
-        eng.index_flat(keys, arena, offs, field_weights)
-        eng.save_host_index(path)
-    barrier()
-    if local_rank != 0:
-        eng.index_from_host_cache(path)
-    barrier()
-    if local_rank == 0:
-        try:
-            os.remove(path)
-        except OSError:
-            pass
+    saves the host index into a private directory under `cache_dir`; the node's other ranks wait (`barrier()`: any barrier over the ranks, e.g.
+    torch.distributed.barrier), read the arrays back and upload their own shard; the leader removes file and directory after a second barrier.
+    `tag` must be the same on the ranks of a node and unique per job (e.g. MASTER_PORT).  Every rank ends up with the same host index as if it had
+    called index_flat itself.  A rank that fails still takes part in both barriers and raises afterwards: a leader that cannot index or save leaves
+    no file, so its followers fail to open it and raise as well - nobody waits for a peer that has gone."""
+    err = None
+    path = None
+    try:
+        if local_rank == 0:
+            path = os.path.join(_job_dir(cache_dir, tag, create=True), "host_index.bin")
+            eng.set_build_threads(node_cpus)
+            eng.index_flat(keys, arena, offs, field_weights)
+            eng.save_host_index(path)
+    except BaseException as e:              # noqa: BLE001 - re-raised below, after the barriers the peers are waiting in
+        err = e
+    try:
+        barrier()
+        if err is None and local_rank != 0:
+            try:
+                d = _job_dir(cache_dir, tag, create=False)
+                eng.index_from_host_cache(os.path.join(d, "host_index.bin"))
+            except BaseException as e:      # noqa: BLE001
+                err = e
+        barrier()
+    finally:
+        if local_rank == 0:
+            for f in ("host_index.bin", "host_index.bin.tmp"):
+                try:
+                    os.remove(os.path.join(cache_dir, f"infx_{os.getuid()}_{tag}", f))
+                except OSError:
+                    pass
+            try:
+                os.rmdir(os.path.join(cache_dir, f"infx_{os.getuid()}_{tag}"))
+            except OSError:
+                pass
+    if err is not None:
+        raise err
 
 
 class ShardSession:

@@ -54,7 +54,9 @@ def test_cached_host_index_plans_like_the_built_one(built):
 def test_foreign_truncated_or_mismatching_cache_is_refused(built, tmp_path):
     s, e, path = built
     blob = open(path, "rb").read()
-    cases = {"truncated": blob[:len(blob) // 2], "foreign": b"INFDX2" + blob[6:], "tail": blob[:-8] + b"\0" * 8, "empty": b""}
+    mid = len(blob) // 2
+    flipped = blob[:mid] + bytes([blob[mid] ^ 0x10]) + blob[mid + 1:]          # one bit inside an array: the lengths still add up, the checksum does not
+    cases = {"truncated": blob[:len(blob) // 2], "foreign": b"INFDX2" + blob[6:], "tail": blob[:-8] + b"\0" * 8, "empty": b"", "flipped": flipped}
     for name, data in cases.items():
         p = str(tmp_path / (name + ".bin"))
         open(p, "wb").write(data)
@@ -69,6 +71,25 @@ def test_foreign_truncated_or_mismatching_cache_is_refused(built, tmp_path):
     missing = SearchEngine.create_default(device=-1, threads=2)
     with pytest.raises(E.InfidexError):
         missing.index_from_host_cache(str(tmp_path / "nope.bin"))
+
+
+def test_cache_file_is_created_exclusively(built, tmp_path):
+    """A link planted at the writer's temporary path is replaced, not written through; a link at the final path is not read through."""
+    s, e, path = built
+    victim = tmp_path / "victim.txt"
+    victim.write_bytes(b"do not touch")
+    target = str(tmp_path / "host.bin")
+    os.symlink(str(victim), target + ".tmp")
+    e.save_host_index(target)
+    assert victim.read_bytes() == b"do not touch"
+    assert not os.path.islink(target) and os.path.getsize(target) == os.path.getsize(path)
+    assert (os.stat(target).st_mode & 0o777) == 0o600
+    link = str(tmp_path / "link.bin")
+    os.symlink(target, link)
+    f = SearchEngine.create_default(device=-1, threads=2)
+    f.add_synonym("street", "road")
+    with pytest.raises(E.InfidexError):
+        f.index_from_host_cache(link)
 
 
 def _free_port():
@@ -118,3 +139,37 @@ def test_two_ranks_one_build(tmp_path):
     texts = _queries(s, 60)
     sig = [(p["mode"], p["prefix_set"], p["n_and"], p["term_ids"].tolist(), p["df"].tolist(), p["idf"].view(np.uint32).tolist()) for p in (solo.plan(t) for t in texts)]
     assert sig == sig0
+
+
+def _failing_rank(rank, world, port, cache_dir, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from infidex_amd.sharded import create_sharded_engine, index_flat_per_node
+    s = Synth(2, docs=3000)
+    arena, offs = s.docs()
+    eng = create_sharded_engine(rank, world, -1, threads=2)
+    if rank == 0:
+        offs = offs.copy(); offs[7] = offs[9] + 5                       # descending field offsets: the leader's index_flat refuses them
+    try:
+        index_flat_per_node(eng, dist.barrier, rank, 2, None, arena, offs, s.field_weights, tag=str(port), cache_dir=cache_dir)
+        q.put((rank, "ok", sorted(os.listdir(cache_dir))))
+    except Exception as e:                  # noqa: BLE001
+        q.put((rank, type(e).__name__, sorted(os.listdir(cache_dir))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_leader_fails_every_rank_instead_of_hanging(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_failing_rank, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+    assert got[0][1] != "ok" and got[1][1] != "ok", got          # both raised, nobody waited for the other
+    assert got[0][2] == []                                       # nothing left behind
