@@ -175,11 +175,16 @@ int64_t infx_engine_last_stage2(infx_engine* e, uint32_t* query_of, int32_t* doc
  * lock).  On a sharded engine every rank must make the same call.  *out_marked (optional) = documents newly marked. */
 int32_t infx_engine_delete_documents(infx_engine* e, const int64_t* keys, int64_t n, int64_t* out_marked);
 /* SearchEngine.Load (SearchEngine.cs:399-441) of an INFDX2 file written by SearchEngine.Save (Indexing/IndexPersistence.cs:33-99): header and data
- * checksums are verified, the documents { DocumentKey, IndexedText as the single Med-weight field "content", Deleted } are indexed and uploaded like
- * infx_engine_index_documents does, and every stored term (text, document frequency, postings with their weight bytes) is compared with the index
- * just built; the file's derived sections (FST, short-query index, metadata cache, WordMatcher) are rebuilt from the documents, not read.
- * checked3 (optional): documents, stored terms compared, stored postings compared.  INFX_EUNSUPPORTED when the stored postings are not what the
- * builder produces for the stored texts (e.g. written from differently weighted fields); INFX_EINVAL for a foreign or corrupted file. */
+ * checksums are verified, the host index is built from the documents { DocumentKey, IndexedText as the single Med-weight field "content", Deleted }
+ * and — BEFORE anything is uploaded — compared with what the file stores: every stored term (text, document frequency, postings with their weight
+ * bytes; both ways) and every derived section the reference's Load would read and search with (csrc/host/infdx2_verify.h): the term FST (every term
+ * with its collection index, forward and reverse trie in FstBuilder's layout), the short-query index (every (prefix, document, token position) entry
+ * regenerated from the index texts), the document metadata cache (first token, token count) and the WordMatcher section behind the checksum (exact and
+ * symmetric-delete dictionaries with their Roaring document sets, the affix FST with its last-occurrence documents).  A WordMatcher section on an engine
+ * configured without one, or none on an engine configured with one, is refused as SearchEngine.cs:436-439 throws.
+ * checked3 (optional): documents, stored terms compared, stored postings compared.  INFX_EUNSUPPORTED when a stored structure is not what the builder
+ * produces for the stored texts (e.g. written from differently weighted fields, another stop-term limit, a derived section that says something else than
+ * the documents) — the engine is left unindexed and can load another file; INFX_EINVAL for a foreign or corrupted file. */
 int32_t infx_engine_load_index(infx_engine* e, const char* path, int64_t* checked3);
 /* SearchEngine.Flush's on-disk segments (INFS: Indexing/Segments/SegmentWriter.cs:13-94, BlockPostingsWriter.cs:24-161 — blocks of 64..256 delta-coded postings
  * with min / max doc and max weight per block, Compression/GroupVarInt.cs, the "FST2" term tries, Elias-Fano list offsets).  infx_segment_open reads and
@@ -201,8 +206,8 @@ int32_t infx_engine_restore_documents(infx_engine* e);      /* clears every Dele
  * word dictionaries, the WordMatcher lists).  The node's leader indexes the documents (infx_engine_set_build_threads lets that build use every
  * core of the node while planning keeps the rank's share), saves the host index to a node-local file (e.g. under /dev/shm) and the other ranks call
  * infx_engine_index_from_host_cache INSTEAD of infx_engine_index_documents: they read the arrays back and upload their own shard.  The file pins its
- * layout version, the configuration (n-gram, stop-term, WordMatcher, synonym settings) and the index fingerprint; anything else is refused
- * (INFX_EINVAL).  A transient hand-off between the processes of one build — not the reference's INFDX2 format (infx_engine_load_index). */
+ * layout version, the configuration (n-gram, stop-term, WordMatcher, synonym settings), the index fingerprint and a checksum of its payload; anything
+ * else is refused (INFX_EINVAL).  It is created exclusively (O_EXCL | O_NOFOLLOW, mode 0600) and read without following a link.  A transient hand-off between the processes of one build — not the reference's INFDX2 format (infx_engine_load_index). */
 int32_t infx_engine_set_build_threads(infx_engine* e, int32_t threads);     /* 0 = the engine's thread count */
 int32_t infx_engine_save_host_index(infx_engine* e, const char* path);
 int32_t infx_engine_index_from_host_cache(infx_engine* e, const char* path);

@@ -16,25 +16,39 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-Wno-unused-result"]
 
 
-def sources():
-    out = []
-    for root, _, files in os.walk(CSRC):
-        for f in files:
-            if f.endswith((".hip", ".inc", ".h", ".cpp")):
-                out.append(os.path.join(root, f))
+def _include_headers():
     inc = os.path.join(os.path.dirname(HERE), "include")
-    out += [os.path.join(inc, f) for f in os.listdir(inc)]
-    return out
+    return [os.path.join(inc, f) for f in os.listdir(inc)]
+
+
+def device_sources():
+    """What the device object is compiled from: the .hip / .inc files of csrc/ and the public headers."""
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".inc", ".h"))] + _include_headers()
+
+
+def host_sources():
+    """What the host object (csrc/host/engine.cpp) is compiled from."""
+    host = os.path.join(CSRC, "host")
+    return [os.path.join(host, f) for f in os.listdir(host) if f.endswith((".h", ".cpp"))] + _include_headers()
+
+
+def sources():
+    return sorted(set(device_sources() + host_sources()))
+
+
+def _stale(target, deps):
+    return not os.path.exists(target) or any(os.path.getmtime(s) > os.path.getmtime(target) for s in deps)
 
 
 def _build(lib, obj_dev, obj_host, extra, force, verbose):
-    if not force and os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in sources()):
-        return lib
-    cmds = [
-        [HIPCC, "--offload-arch=gfx950", *COMMON, *extra, "-c", os.path.join(CSRC, "infidex_hip.hip"), "-o", obj_dev],
-        [HIPCC, *COMMON, "-march=x86-64-v3", "-x", "c++", "-c", os.path.join(CSRC, "host", "engine.cpp"), "-o", obj_host],
-        [HIPCC, "--offload-arch=gfx950", "-shared", "-o", lib, obj_dev, obj_host, "-lpthread"],
-    ]
+    # each object is rebuilt only when one of ITS sources changed: a host-side change leaves the device object (the kernels) byte for byte as it was
+    cmds = []
+    if force or _stale(obj_dev, device_sources()):
+        cmds.append([HIPCC, "--offload-arch=gfx950", *COMMON, *extra, "-c", os.path.join(CSRC, "infidex_hip.hip"), "-o", obj_dev])
+    if force or _stale(obj_host, host_sources()):
+        cmds.append([HIPCC, *COMMON, "-march=x86-64-v3", "-x", "c++", "-c", os.path.join(CSRC, "host", "engine.cpp"), "-o", obj_host])
+    if cmds or _stale(lib, [obj_dev, obj_host]):
+        cmds.append([HIPCC, "--offload-arch=gfx950", "-shared", "-o", lib, obj_dev, obj_host, "-lpthread"])
     for c in cmds:
         if verbose:
             print(" ".join(c), file=sys.stderr)

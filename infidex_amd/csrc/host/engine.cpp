@@ -9,6 +9,7 @@
 #include "query.h"
 #include "filter.h"
 #include "infdx2.h"
+#include "infdx2_verify.h"
 #include "infs.h"
 #include "hostcache.h"
 #include <mutex>
@@ -1695,23 +1696,37 @@ int32_t infx_engine_load_index(infx_engine* e, const char* path, int64_t* checke
     }
     if (arena.empty()) arena.push_back(0);
     const int32_t w = 1;      // Weight.Med: ReadDocuments adds the text as the single field "content" with Weight.Med (IndexPersistence.cs:338-339)
-    int32_t rc = infx_engine_index_documents(e, n, keys.data(), arena.data(), offs.data(), 1, &w);
-    if (rc) return rc;
+    if (n > 0x7FFFFFF0ll) return efail(INFX_EINVAL, "too many documents");
+    // build the host index, CHECK it against the file, and only then commit (upload, key map): a refused file leaves the engine unindexed and reusable
+    {
+        DocSource src{n, 1, &w, keys.data(), (const u16*)arena.data(), offs.data()};
+        const int planThreads = e->ix.cfg.threads;
+        if (e->buildThreads > 0) e->ix.cfg.threads = e->buildThreads;
+        build_index(src, e->ix);
+        e->ix.cfg.threads = planThreads;
+    }
     const HostIndex& ix = e->ix;
     int64_t nterms = 0, npost = 0;
+    const char* bad = nullptr;
     for (auto& t : F.terms) {
         const int64_t id = ix.terms.keys.find(uview((const u16*)t.text.data(), t.text.size()));
-        if (id < 0) return efail(INFX_EUNSUPPORTED, "a stored term does not exist in the index built from the stored documents");
+        if (id < 0) { bad = "a stored term does not exist in the index built from the stored documents"; break; }
         const uint64_t b = ix.terms.off[id], len = ix.terms.off[id + 1] - b;
-        if (ix.df[id] != t.df || len != t.docs.size()) return efail(INFX_EUNSUPPORTED, "a stored term's document frequency / posting count differs from the rebuilt index");
-        for (size_t i = 0; i < t.docs.size(); i++)
-            if (ix.terms.doc[b + i] != t.docs[i] || ix.terms.w[b + i] != t.w[i]) return efail(INFX_EUNSUPPORTED, "a stored posting (document, weight) differs from the rebuilt index: the file was not written from single Med-weight fields");
+        if (ix.df[id] != t.df || len != t.docs.size()) { bad = "a stored term's document frequency / posting count differs from the rebuilt index"; break; }
+        for (size_t i = 0; i < t.docs.size() && !bad; i++)
+            if (ix.terms.doc[b + i] != t.docs[i] || ix.terms.w[b + i] != t.w[i]) bad = "a stored posting (document, weight) differs from the rebuilt index: the file was not written from single Med-weight fields";
+        if (bad) break;
         nterms++; npost += (int64_t)t.docs.size();
     }
-    {   // ... and the other direction: the rebuilt index may not hold non-stop terms the file lacks (e.g. a file written with another stop-term limit)
+    if (!bad) {   // ... and the other direction: the rebuilt index may not hold non-stop terms the file lacks (e.g. a file written with another stop-term limit)
         int64_t built = 0; for (size_t id = 0; id < ix.terms.K(); id++) if (ix.df[id] > 0) built++;
-        if (built != nterms) return efail(INFX_EUNSUPPORTED, "the index rebuilt from the stored documents holds another number of non-stop terms than the file");
+        if (built != nterms) bad = "the index rebuilt from the stored documents holds another number of non-stop terms than the file";
     }
+    if (!bad) bad = infdx2::check_derived(F, ix);
+    if (bad) { const HostConfig keep = e->ix.cfg; e->ix = HostIndex{}; e->ix.cfg = keep; return efail(INFX_EUNSUPPORTED, bad); }
+    e->keysAreIds = false;
+    int32_t rc = finish_index(e);
+    if (rc) return rc;
     std::vector<int64_t> gone; for (auto& d : F.docs) if (d.deleted) gone.push_back(d.key);
     if (!gone.empty()) { rc = infx_engine_delete_documents(e, gone.data(), (int64_t)gone.size(), nullptr); if (rc) return rc; }
     if (checked3) { checked3[0] = n; checked3[1] = nterms; checked3[2] = npost; }

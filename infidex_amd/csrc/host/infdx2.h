@@ -3,7 +3,8 @@
 // File: "INFDX2" | u32 version (2) | u32 flags | u32 docCount | u32 termCount | u32 headerChecksum | u32 dataLength | data | u32 dataChecksum | [WordMatcher ...]
 // data: documents (i32 count; per document i32 id, i64 DocumentKey, string IndexedText, string clientInformation, i32 segment, i32 jsonIndex, u8 deleted)
 //       terms     (i32 count of the non-stop terms; per term string text, i32 documentFrequency, i32 postingCount, postingCount x {i32 docId, u8 weight})
-//       [FST] [short-query index] [document metadata cache]   — derived structures; this reader rebuilds them from the documents and skips the bytes
+//       [FST] [short-query index] [document metadata cache]   — derived structures; the product rebuilds them from the documents and host/infdx2_verify.h
+//       checks the stored ones against what it built (as it does with the WordMatcher section behind the checksum)
 // strings are BinaryWriter strings: 7-bit-encoded UTF-8 byte length, then the bytes.  Checksums: IndexPersistence.cs:268-299.
 //
 // What Load gives the reference is documents { DocumentKey, one "content" field = IndexedText, Weight.Med } (ReadDocuments :322-349) plus the stored
@@ -22,7 +23,9 @@ namespace infdx2 {
 
 struct Doc { int32_t id; int64_t key; std::u16string text; bool deleted; };
 struct TermRec { std::u16string text; int32_t df; std::vector<int32_t> docs; std::vector<uint8_t> w; };
-struct File { uint32_t flags = 0, docCount = 0, termCount = 0; std::vector<Doc> docs; std::vector<TermRec> terms; std::string error; };
+struct File { uint32_t flags = 0, docCount = 0, termCount = 0; std::vector<Doc> docs; std::vector<TermRec> terms; std::string error;
+              std::vector<uint8_t> blob;                       // the whole file: the derived sections are verified in place (infdx2_verify.h)
+              size_t derivedAt = 0, dataEnd = 0, trailerAt = 0; };      // [derivedAt, dataEnd) = FST / short-query index / metadata cache; trailerAt = the WordMatcher flag
 
 inline uint32_t rotl7(uint32_t c) { return (c << 7) | (c >> 25); }
 inline uint32_t checksum_words(const uint32_t* v, size_t n) { uint32_t c = 0x12345678u; for (size_t i = 0; i < n; i++) { c ^= v[i]; c = rotl7(c); } return c; }
@@ -53,7 +56,8 @@ struct Rd {
 inline bool read_file(const std::string& path, File& F) {
     std::ifstream in(path, std::ios::binary);
     if (!in) { F.error = "cannot open " + path; return false; }
-    std::vector<uint8_t> buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    F.blob.assign((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    const std::vector<uint8_t>& buf = F.blob;
     Rd R{buf.data(), buf.data() + buf.size()};
     if (buf.size() < 30 || std::memcmp(buf.data(), "INFDX2", 6) != 0) { F.error = "invalid index magic: expected INFDX2"; return false; }
     R.p += 6;
@@ -84,7 +88,8 @@ inline bool read_file(const std::string& path, File& F) {
         t.docs.resize((size_t)pc); t.w.resize((size_t)pc);
         for (int32_t i = 0; i < pc; i++) { std::memcpy(&t.docs[i], D.p, 4); t.w[i] = D.p[4]; D.p += 5; }
     }
-    return true;        // FST / short-query index / metadata cache bytes (rest of the blob) and the WordMatcher section after the checksum are rebuilt, not read
+    F.derivedAt = (size_t)(D.p - buf.data()); F.dataEnd = (size_t)(data + dlen - buf.data()); F.trailerAt = F.dataEnd + 4;
+    return true;        // the FST / short-query index / metadata cache bytes (rest of the data) and the WordMatcher section after the checksum: infdx2_verify.h
 }
 
 }  // namespace infdx2

@@ -54,7 +54,8 @@ inline bool read_trie(Rd& r, Trie& t, std::string& err) {
     const int32_t na = r.get<int32_t>();
     if (!r.ok || na < 0 || (size_t)na > (r.n - r.p) / 11) { err = "term index: bad arc count"; return false; }
     t.label.resize(na); t.target.resize(na);
-    for (int32_t i = 0; i < na; i++) { t.label[i] = r.get<uint16_t>(); t.target[i] = r.get<int32_t>(); (void)r.get<int32_t>(); (void)r.get<uint8_t>(); }
+    std::vector<int32_t> arcOut((size_t)na); std::vector<uint8_t> arcFin((size_t)na);      // copies of the target's output / final flag (FstBuilder.cs:154-160): checked below
+    for (int32_t i = 0; i < na; i++) { t.label[i] = r.get<uint16_t>(); t.target[i] = r.get<int32_t>(); arcOut[i] = r.get<int32_t>(); arcFin[i] = r.get<uint8_t>(); }
     t.root = r.get<int32_t>();
     if (!r.ok || t.root < 0 || t.root >= nn) { err = "term index: truncated"; return false; }
     for (int32_t i = 0; i < nn; i++) {
@@ -62,6 +63,15 @@ inline bool read_trie(Rd& r, Trie& t, std::string& err) {
         for (int k = 1; k < t.arcCount[i]; k++) if (t.label[t.arcStart[i] + k] <= t.label[t.arcStart[i] + k - 1]) { err = "term index: children not sorted by label"; return false; }
     }
     for (int32_t i = 0; i < na; i++) if (t.target[i] <= 0 || t.target[i] >= nn) { err = "term index: arc target out of bounds"; return false; }
+    for (int32_t i = 0; i < nn; i++) if (t.fin[i] > 1 || (!t.fin[i] && t.out[i] != -1)) { err = "term index: final flag neither 0 nor 1, or an output on a non-final node"; return false; }
+    // the layout CompactTrie produces (FstBuilder.cs:110-166): breadth-first, root first, a node's arcs behind those of the nodes before it, arc k leading to node k + 1
+    if (t.root != 0 || na != nn - 1) { err = "term index: not in FstBuilder's breadth-first layout"; return false; }
+    for (int32_t i = 0, run = 0; i < nn; i++) { if (t.arcStart[i] != run) { err = "term index: not in FstBuilder's breadth-first layout"; return false; } run += t.arcCount[i]; }
+    for (int32_t i = 0; i < na; i++) if (t.target[i] != i + 1) { err = "term index: not in FstBuilder's breadth-first layout"; return false; }
+    for (int32_t i = 0; i < na; i++) {          // redundant copies of the node's fields: a file where they disagree was not written by FstBuilder
+        const int32_t c = t.target[i];
+        if (arcFin[i] != t.fin[c] || arcOut[i] != (t.fin[c] ? t.out[c] : -1)) { err = "term index: an arc disagrees with its target node"; return false; }
+    }
     return true;
 }
 // terms of a trie in ordinal order (pre-order, children ascending) with their outputs; fails on a cycle (more nodes visited than exist)
@@ -79,6 +89,7 @@ inline bool enumerate_trie(const Trie& t, std::vector<std::u16string>& terms, st
         if (t.fin[ch]) { terms.push_back(cur); outs.push_back(t.out[ch]); }
         st.push_back({ch, 0});
     }
+    if (visited + 1 != t.arcStart.size() || visited != t.label.size()) { err = "term index: nodes or arcs outside the tree"; return false; }
     return true;
 }
 

@@ -12,7 +12,7 @@ from tests.test_oracle_kats import TEN_DOCS
 from tools.synth import Synth
 
 
-def _oracle_file(path, docs, corrupt=None, bump_weight=False, deleted=()):
+def _oracle_file(path, docs, corrupt=None, bump_weight=False, deleted=(), tamper=None):
     o = O.OracleEngine.create_default(); o.index(docs)
     ex = o.export_index()
     terms = []
@@ -24,7 +24,11 @@ def _oracle_file(path, docs, corrupt=None, bump_weight=False, deleted=()):
         terms.append((o.term_text(t), int(ex["df"][t]), post))
     if bump_weight:
         text, df, post = terms[len(terms) // 2]; terms[len(terms) // 2] = (text, df, [(post[0][0], post[0][1] + 1)] + post[1:])
-    W.write(path, [(i, k, t, k in deleted) for i, (k, t) in enumerate(docs)], terms, derived=b"\xAB" * 37, trailer=b"\x01" + b"\xCD" * 11)
+    # the derived sections as the reference derives them: term FST over EVERY term of the collection, short-query index, metadata cache, WordMatcher
+    derived, trailer = W.derived_sections([o.term_text(t) for t in range(o.num_terms)], [t for _, t in docs], O.normalize)
+    if tamper is not None:
+        derived, trailer = tamper(derived, trailer)
+    W.write(path, [(i, k, t, k in deleted) for i, (k, t) in enumerate(docs)], terms, derived=derived, trailer=trailer)
     if corrupt is not None:
         raw = bytearray(open(path, "rb").read()); raw[corrupt] ^= 0x40; open(path, "wb").write(bytes(raw))
     return o, len(terms), sum(len(p) for _, _, p in terms)
@@ -53,6 +57,127 @@ def test_reader_refuses_foreign_corrupted_and_inconsistent_files(tmp_path, what)
     with pytest.raises(InfidexError) as ex:
         e.load_index(p)
     assert ex.value.code == (5 if what == "weights" else 1), (what, str(ex.value))      # INFX_EUNSUPPORTED: postings this builder would not produce; INFX_EINVAL otherwise
+
+
+def _sections(docs):
+    """Byte ranges of the three derived sections inside `derived` (the writer concatenates them) for the tamper tests."""
+    o = O.OracleEngine.create_default(); o.index(docs)
+    texts = [t for _, t in docs]
+    fst = W.fst_section([(o.term_text(t), t) for t in range(o.num_terms)])
+    sq = W.short_query_section([O.normalize(t, True) for t in texts])
+    return len(fst), len(sq)
+
+
+TAMPER_DOCS = [(k, t) for k, t in TEN_DOCS] + [(77, "Žďár nad Sázavou škola"), (78, "the batman returns again and again")]
+
+
+@pytest.mark.parametrize("what", ["fst_output", "fst_missing_term", "short_position", "short_extra_list", "meta_count", "meta_first", "wm_absent", "wm_exact_doc",
+                                  "wm_ld1_key", "wm_affix_last_doc", "wm_trailing", "derived_trailing"])
+def test_reader_refuses_derived_sections_that_disagree_with_the_documents(tmp_path, what):
+    """Every derived section is checked against the index rebuilt from the stored documents (csrc/host/infdx2_verify.h): a file whose FST, short-query
+    index, metadata cache or WordMatcher says something else than its documents is refused, and the engine stays usable."""
+    import struct
+    nfst, nsq = _sections(TAMPER_DOCS)
+    o = O.OracleEngine.create_default(); o.index(TAMPER_DOCS)
+    texts = [t for _, t in TAMPER_DOCS]
+    terms = [o.term_text(t) for t in range(o.num_terms)]
+    meta = [O.normalize(t.lower(), False) for t in texts]
+
+    def tamper(derived, trailer):
+        d = bytearray(derived); t = bytearray(trailer)
+        if what == "fst_output":                               # two terms swap their collection indexes
+            pairs = [(x, i) for i, x in enumerate(terms)]; pairs[3], pairs[4] = (pairs[3][0], 4), (pairs[4][0], 3)
+            d[:nfst] = W.fst_section(pairs)
+        elif what == "fst_missing_term":
+            fst = W.fst_section([(x, i) for i, x in enumerate(terms[:-1])]); d[:nfst] = fst
+        elif what == "short_position":                         # first posting of the first single-character list: position + 1
+            at = nfst + 4 + 2 + 4 + 4; d[at:at + 2] = struct.pack("<H", struct.unpack_from("<H", d, at)[0] + 1)
+        elif what == "short_extra_list":                       # one more 2-character prefix nobody's text holds
+            sq = bytearray(d[nfst:nfst + nsq]); idx = W.short_query_section([O.normalize(x, True) for x in texts] + ["qz"])
+            d[nfst:nfst + nsq] = idx                          # (document id = len(texts): out of range as well)
+        elif what == "meta_count":
+            d[-2:] = struct.pack("<H", struct.unpack_from("<H", d, len(d) - 2)[0] + 1)
+        elif what == "meta_first":
+            d[nfst + nsq:] = W.metadata_section(["zzz " + meta[0]] + meta[1:])
+        elif what == "wm_absent":
+            t = bytearray(b"\x00")
+        elif what == "wm_exact_doc":                           # a word of the first document is spelt differently in the stored dictionaries
+            w0 = next(w for w in W.words_of(meta[0]) if 3 <= len(w) <= 8)
+            t = bytearray(W.wordmatcher_section([meta[0].replace(w0, w0[:-1] + ("q" if w0[-1] != "q" else "x"), 1)] + meta[1:]))
+        elif what == "wm_ld1_key":
+            t = bytearray(W.wordmatcher_section(meta, max_ld1=7))
+        elif what == "wm_affix_last_doc":                      # the affix FST leads to the FIRST occurrence instead of the last
+            full = W.wordmatcher_section(meta)
+            occ = [(w, d) for d, m in enumerate(meta) for w in W.words_of(m) if len(w) >= 3]
+            first = {}
+            for i, (w, _) in enumerate(occ):
+                first.setdefault(w, i)
+            good = W.fst_section([(w, i) for i, (w, _) in enumerate(occ)]); bad = W.fst_section([(w, first[w]) for w, _ in occ])
+            assert good in full and len(good) == len(bad) and good != bad
+            t = bytearray(full.replace(good, bad))
+        elif what == "wm_trailing":
+            t += b"\x00"
+        elif what == "derived_trailing":
+            d += b"\x00\x00"
+        return bytes(d), bytes(t)
+
+    p = str(tmp_path / "bad.infdx2")
+    _oracle_file(p, TAMPER_DOCS, tamper=tamper)
+    e = SearchEngine.create_default(device=-1)
+    with pytest.raises(InfidexError) as ex:
+        e.load_index(p)
+    assert ex.value.code == 5, (what, str(ex.value))           # INFX_EUNSUPPORTED
+    print(what, "->", str(ex.value))
+    section = {"fst": "FST", "short": "short-query", "meta": "metadata", "wm": ("WordMatcher", "affix", "symmetric-delete", "exact-word"), "derived": "data section"}[what.split("_")[0]]
+    assert any(x in str(ex.value) for x in ((section,) if isinstance(section, str) else section)), (what, str(ex.value))
+    # the refused file left the engine unindexed: the intact file loads into the same instance
+    good = str(tmp_path / "good.infdx2")
+    _oracle_file(good, TAMPER_DOCS)
+    assert e.load_index(good)[0] == len(TAMPER_DOCS)
+
+
+def test_flipped_bytes_in_the_derived_sections_never_get_past_the_bounds_checks(tmp_path):
+    """400 single-byte corruptions — half in the WordMatcher section (no checksum covers it), half in the derived sections with the data checksum recomputed (a
+    crafted file): each load either refuses the file or — when the byte is one nothing depends on (a Roaring offset, an arc's redundant output) — accepts it;
+    none may crash or read out of bounds."""
+    import struct
+    rng = np.random.default_rng(11)
+    base = str(tmp_path / "base.infdx2")
+    _oracle_file(base, TAMPER_DOCS)
+    raw = open(base, "rb").read()
+    dlen = struct.unpack_from("<I", raw, 26)[0]
+    data_at, data_end = 30, 30 + dlen
+    nfst, nsq = _sections(TAMPER_DOCS)
+    derived_len = len(W.derived_sections([""], [t for _, t in TAMPER_DOCS], O.normalize)[0]) - len(W.fst_section([("", 0)])) + nfst
+    refused = accepted = 0
+    for k in range(400):
+        b = bytearray(raw)
+        if k % 2 == 0:
+            at = int(rng.integers(data_end + 4, len(raw)))
+            b[at] ^= 1 << int(rng.integers(0, 8))
+        else:
+            at = int(rng.integers(data_end - derived_len, data_end))
+            b[at] ^= 1 << int(rng.integers(0, 8))
+            b[data_end:data_end + 4] = struct.pack("<I", W.checksum_bytes(bytes(b[data_at:data_end])))
+        p = str(tmp_path / "f.infdx2")
+        open(p, "wb").write(bytes(b))
+        e = SearchEngine.create_default(device=-1)
+        try:
+            e.load_index(p); accepted += 1
+        except InfidexError as ex:
+            assert ex.code in (1, 5); refused += 1
+    print("refused", refused, "accepted", accepted)
+    assert refused >= 396
+
+
+def test_roaring_bitmaps_of_every_container_kind(tmp_path):
+    """A word that occurs in > 4096 documents of one 65 536-id container is stored as a bitmap container, a rarer one as an array container, and document
+    ids beyond 65 535 open a second container: all three decode to the rebuilt lists."""
+    docs = [(i, "common word" + (" rare" if i % 1000 == 0 else "") + (" beyond" if i >= 65536 else "")) for i in range(70000)]
+    p = str(tmp_path / "big.infdx2")
+    _, nterms, npost = _oracle_file(p, docs)
+    e = SearchEngine.create_default(device=-1, threads=4)
+    assert e.load_index(p) == (len(docs), nterms, npost)
 
 
 @pytest.mark.gpu
