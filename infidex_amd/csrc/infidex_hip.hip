@@ -318,10 +318,10 @@ struct infx_stream {
 };
 
 #define S2_HUGE_POOL_U16 (32u << 20)      // token-table pool of k_stage2's over-long-document pass: 64 MB per stream (a 700-word row takes 5.7 KB, a 32 768-token one 265 KB)
-static int32_t grow(void** p, size_t* cap, size_t need);
+static int32_t grow(infx_stream* s, void** p, size_t* cap, size_t need);
 static int32_t s2_huge_ready(infx_stream* s) {      // pool + bump counter of the over-long-document pass (allocated at the stream's first Stage-2 launch)
-    int32_t rc = grow(&s->dHugeWs, &s->capHugeWs, (size_t)S2_HUGE_POOL_U16 * 2); if (rc) return rc;
-    rc = grow(&s->dHugeCnt, &s->capHugeCnt, 16); if (rc) return rc;
+    int32_t rc = grow(s, &s->dHugeWs, &s->capHugeWs, (size_t)S2_HUGE_POOL_U16 * 2); if (rc) return rc;
+    rc = grow(s, &s->dHugeCnt, &s->capHugeCnt, 16); if (rc) return rc;
     if (hipMemsetAsync(s->dHugeCnt, 0, 4, s->st) != hipSuccess) return fail(INFX_EHIP, "hipMemsetAsync failed%s");
     return INFX_OK;
 }
@@ -331,11 +331,10 @@ static int32_t s2_huge_ready(infx_stream* s) {      // pool + bump counter of th
 // in flight at that moment, spinning until the peer rank's matching collective runs, while on the peer the roles are swapped: neither rank can enqueue what the
 // other waits for.  Workspaces are therefore never freed while their stream lives: the outgrown buffer is parked on the stream (freed by infx_stream_destroy);
 // growth is geometric, so the parked buffers add up to less than the live one.
-static thread_local infx_stream* tl_stream = nullptr;      // the stream of the API call this thread is in (set by pin_reset)
-static void ws_release(void* p);
-static int32_t grow(void** p, size_t* cap, size_t need) {
+static void ws_release(infx_stream* s, void* p);
+static int32_t grow(infx_stream* s, void** p, size_t* cap, size_t need) {
     if (need <= *cap) return INFX_OK;
-    if (*p) { if (tl_stream) tl_stream->parked.push_back(*p); else hipFree(*p); }
+    if (*p) s->parked.push_back(*p);
     // a quarter of headroom: batches of one workload differ by a few per cent, and a reallocation (hipFree + hipMalloc synchronise the device) in a
     // stream's second batch would stall every other stream's batch in flight
     size_t n = std::max(need + need / 4 + 4096, *cap * 2);
@@ -345,8 +344,8 @@ static int32_t grow(void** p, size_t* cap, size_t need) {
     if (dbgGrow) fprintf(stderr, "[infx] grow: %zu -> %zu bytes (need %zu), hipMalloc took %.2f ms\n", *cap, n, need, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count());
     *cap = n; return INFX_OK;
 }
-static void ws_release(void* p) { if (!p) return; if (tl_stream) tl_stream->parked.push_back(p); else hipFree(p); }
-#define GROW(p, cap, need) do { int32_t rc_ = grow((void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)
+static void ws_release(infx_stream* s, void* p) { if (p) s->parked.push_back(p); }
+#define GROW(p, cap, need) do { int32_t rc_ = grow(s, (void**)&(p), &(cap), (need)); if (rc_) return rc_; } while (0)      /* `s`: the stream of the enclosing call */
 
 // Stage-2 launches: the register budget of the fast variant is selectable for tuning (INFX_S2_WAVES = 2, 4 or 6 waves per SIMD)
 static int s2_waves() { static const int w = [] { const char* e = getenv("INFX_S2_WAVES"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4 || v == 6 || v == 8) ? v : S2_MIN_WAVES; }(); return w; }
@@ -400,7 +399,6 @@ static int32_t stream_sync(infx_stream* s) {
     return INFX_OK;
 }
 static int32_t pin_reset(infx_stream* s) {     // start of an API call: the staging of the previous call must have been consumed
-    tl_stream = s;
     // Outputs still pending here belong to a call that returned before its own synchronisation (an error path): their destinations
     // (often that call's stack variables) are gone, so they are dropped, never copied.
     s->pendingOut.clear();
@@ -936,7 +934,6 @@ int32_t infx_comm_allgather(infx_stream* s, const void* send, void* recv, uint64
 int32_t infx_stream_scratch(infx_stream* s, int32_t slot, uint64_t bytes, void** out) {
     if (!s || !out || slot < 0 || slot >= 16) return fail(INFX_EINVAL, "bad scratch arguments%s");
     HIPCHK(hipSetDevice(s->ix->cfg.device));
-    tl_stream = s;
     if (bytes > s->capScratch[slot]) {
         if (s->unsynced) { int32_t rc_ = stream_sync(s); if (rc_) return rc_; }      // work queued on the old buffer
         GROW(s->scratch[slot], s->capScratch[slot], (size_t)bytes);
@@ -1026,7 +1023,6 @@ void infx_stream_destroy(infx_stream* s) {
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
     for (void* p : s->parked) hipFree(p);
-    if (tl_stream == s) tl_stream = nullptr;
     if (s->comm && rccl_api().ok) rccl_api().destroy(s->comm);
     if (s->st) hipStreamSynchronize(s->st);
     for (auto& c : s->pins) hipHostFree(c.base);
@@ -1139,7 +1135,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     size_t need = (size_t)bound + 64;
     if (need > s->arCap) {
         if (need > ((size_t)1 << 31)) return fail(INFX_ECAPACITY, "candidate superset bound exceeds 2^31 entries; split the batch%s");
-        if (s->arDoc) { ws_release(s->arDoc); ws_release(s->arScore); ws_release(s->arCls); s->arDoc = nullptr; }
+        if (s->arDoc) { ws_release(s, s->arDoc); ws_release(s, s->arScore); ws_release(s, s->arCls); s->arDoc = nullptr; }
         // The bound (sum of the candidate-generating lists' lengths) varies by +-30 % between 1000-query batches of one workload, and a reallocation in the
         // middle of a stream is not free even without hipFree (a multi-GB hipMalloc can wait for the device): twice the first batch's need, doubling after that.
         // ~40 B per row: 5 GB per session at 10 M documents, of 288.
@@ -1152,13 +1148,13 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     // per-row hit masks (2 bits per reference term) for the exact Stage-1 replay: kept when every query of the batch has <= 64 terms
     s->maskWords = !exact_enabled(ix) ? 0 : (maxRef <= 32 ? 1 : (maxRef <= 64 ? 2 : 0));
     if (s->maskWords && s->arCap * (size_t)s->maskWords > s->arMaskCap) {
-        if (s->arMask) { ws_release(s->arMask); s->arMask = nullptr; s->arMaskCap = 0; }
+        if (s->arMask) { ws_release(s, s->arMask); s->arMask = nullptr; s->arMaskCap = 0; }
         const size_t n = s->arCap * (size_t)s->maskWords;
         if (hipMalloc((void**)&s->arMask, n * 8) != hipSuccess) return fail(INFX_ENOMEM, "arena mask allocation failed%s");
         s->arMaskCap = n;
     }
     if (s->maskWords && s->arCap > s->exCap) {
-        if (s->arExc) { ws_release(s->arExc); ws_release(s->exCand); ws_release(s->exOut); s->arExc = nullptr; s->exCand = nullptr; s->exOut = nullptr; s->exCap = 0; }
+        if (s->arExc) { ws_release(s, s->arExc); ws_release(s, s->exCand); ws_release(s, s->exOut); s->arExc = nullptr; s->exCand = nullptr; s->exOut = nullptr; s->exCap = 0; }
         if (hipMalloc((void**)&s->arExc, s->arCap * 4) != hipSuccess || hipMalloc((void**)&s->exCand, s->arCap * 4) != hipSuccess || hipMalloc((void**)&s->exOut, s->arCap * sizeof(infx_hit)) != hipSuccess)
             return fail(INFX_ENOMEM, "exact-replay workspace allocation failed%s");
         s->exCap = s->arCap;
