@@ -1708,8 +1708,9 @@ int32_t infx_engine_load_index(infx_engine* e, const char* path, int64_t* checke
     const HostIndex& ix = e->ix;
     int64_t nterms = 0, npost = 0;
     const char* bad = nullptr;
+    infdx2::LossyMatcher termOf(ix.terms.keys);          // the same text, or the lossy UTF-8 image of a term that holds half a surrogate pair (infdx2.h)
     for (auto& t : F.terms) {
-        const int64_t id = ix.terms.keys.find(uview((const u16*)t.text.data(), t.text.size()));
+        const int64_t id = termOf.match(t.text, [&](uint32_t k) { return ix.df[k] > 0; });
         if (id < 0) { bad = "a stored term does not exist in the index built from the stored documents"; break; }
         const uint64_t b = ix.terms.off[id], len = ix.terms.off[id + 1] - b;
         if (ix.df[id] != t.df || len != t.docs.size()) { bad = "a stored term's document frequency / posting count differs from the rebuilt index"; break; }

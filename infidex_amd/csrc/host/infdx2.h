@@ -35,6 +35,29 @@ inline uint32_t checksum_bytes(const uint8_t* d, size_t n) {
     return c;
 }
 
+// BinaryWriter.Write(string) encodes with Encoding.UTF8, whose replacement fallback writes U+FFFD for a UTF-16 unit that is half of a surrogate pair on its
+// own.  Such strings exist in every index of a text with characters outside the BMP: a 3-gram window, a 1..3-unit token prefix or a single-unit deletion cuts
+// pairs apart.  The reference's own round trip of such an index (PersistenceTests.cs:152-196, one document: U+1F50D) loads fine — its Load compares nothing —
+// so the stored keys are compared with the rebuilt ones THROUGH that mapping: lossy(rebuilt) == stored, several rebuilt keys that collapse onto one stored text
+// are matched in their order of first appearance (the order Dictionary<,> enumerates them in, i.e. the order they were written).
+inline bool has_lone_surrogate(const char16_t* p, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        const char16_t c = p[i];
+        if (c >= 0xD800 && c <= 0xDBFF) { if (i + 1 < n && p[i + 1] >= 0xDC00 && p[i + 1] <= 0xDFFF) { i++; continue; } return true; }
+        if (c >= 0xDC00 && c <= 0xDFFF) return true;
+    }
+    return false;
+}
+inline std::u16string lossy(const char16_t* p, size_t n) {
+    std::u16string o; o.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        const char16_t c = p[i];
+        if (c >= 0xD800 && c <= 0xDBFF && i + 1 < n && p[i + 1] >= 0xDC00 && p[i + 1] <= 0xDFFF) { o.push_back(c); o.push_back(p[++i]); }
+        else o.push_back((c >= 0xD800 && c <= 0xDFFF) ? (char16_t)0xFFFD : c);
+    }
+    return o;
+}
+
 struct Rd {
     const uint8_t* p; const uint8_t* e; bool ok = true;
     template <class T> T get() { T v{}; if ((size_t)(e - p) < sizeof(T)) { ok = false; return v; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }

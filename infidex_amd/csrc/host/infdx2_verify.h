@@ -102,6 +102,37 @@ inline bool rd_fst(infs::Rd& r, infs::Trie& fw, infs::Trie& rv, int32_t& termCou
     return infs::read_trie(r, fw, err) && infs::read_trie(r, rv, err);
 }
 
+// stored key -> id of the rebuilt key it stands for: the same text; else, for a stored text that is the lossy image (infdx2.h: lossy) of rebuilt keys with half a
+// surrogate pair in them, the next of those in id order = order of first appearance = the order the reference wrote them in.  Every rebuilt key is handed out once.
+struct LossyMatcher {
+    const KeyTable& K; std::vector<uint8_t> seen;
+    std::unordered_map<std::u16string, std::pair<std::vector<uint32_t>, size_t>> side; bool built = false;
+    explicit LossyMatcher(const KeyTable& k) : K(k), seen(k.size(), 0) {}
+    template <class Ok> int64_t match(const std::u16string& stored, Ok eligible) {
+        bool replaced = false; for (char16_t c : stored) if (c == 0xFFFD) { replaced = true; break; }
+        if (!replaced) {                                     // no U+FFFD in it: nothing collapses onto this text
+            const int64_t id = K.find(uview(stored.data(), stored.size()));
+            if (id >= 0 && !seen[(size_t)id] && eligible((uint32_t)id)) { seen[(size_t)id] = 1; return id; }
+            return -1;
+        }
+        if (!built) {                                        // candidates of a text: the keys whose lossy image it is and the key that really reads like that, in id order
+            for (uint32_t k = 0; k < (uint32_t)K.size(); k++) { const uview key = K.key(k); if (has_lone_surrogate(key.data(), key.size())) side[lossy(key.data(), key.size())].first.push_back(k); }
+            for (auto& kv : side) { const int64_t id = K.find(uview(kv.first.data(), kv.first.size())); if (id >= 0) { kv.second.first.push_back((uint32_t)id); std::sort(kv.second.first.begin(), kv.second.first.end()); } }
+            built = true;
+        }
+        auto it = side.find(stored);
+        if (it == side.end()) {
+            const int64_t id = K.find(uview(stored.data(), stored.size()));
+            if (id >= 0 && !seen[(size_t)id] && eligible((uint32_t)id)) { seen[(size_t)id] = 1; return id; }
+            return -1;
+        }
+        auto& q = it->second;
+        while (q.second < q.first.size()) { const uint32_t c = q.first[q.second++]; if (!seen[c] && eligible(c)) { seen[c] = 1; return (int64_t)c; } }
+        return -1;
+    }
+    int64_t match(const std::u16string& stored) { return match(stored, [](uint32_t) { return true; }); }
+};
+
 // returns nullptr when every section the file holds agrees with the rebuilt index, else what differs (static text)
 inline const char* check_derived(const File& F, const HostIndex& ix) {
     const HostConfig& cfg = ix.cfg;
@@ -129,36 +160,58 @@ inline const char* check_derived(const File& F, const HostIndex& ix) {
     // ---- short-query index --------------------------------------------------------------------------------------------
     if (F.flags & 2u) {
         struct List { size_t at; uint32_t n, cur; };
-        std::unordered_map<uint64_t, List> lists;                          // key: length << 48 | up to three UTF-16 units
+        std::vector<List> all;                                             // in file order
+        std::unordered_map<uint64_t, std::vector<uint32_t>> byKey;          // key: length << 48 | up to three UTF-16 units -> lists stored under that text (file order)
         auto keyOf = [](const u16* p, int L) { uint64_t k = (uint64_t)L << 48; for (int i = 0; i < L; i++) k |= (uint64_t)p[i] << (16 * i); return k; };
         uint64_t stored = 0;
-        auto take = [&](uint64_t key) -> bool {
+        auto take = [&](uint64_t key, bool mayRepeat) -> bool {
             const int32_t n = r.get<int32_t>();
             if (!r.ok || n < 0 || (size_t)n > (r.n - r.p) / 7) return false;
-            if (!lists.emplace(key, List{r.p, (uint32_t)n, 0u}).second) return false;      // a prefix appears once
+            auto& v = byKey[key];
+            if (!v.empty() && !mayRepeat) return false;                    // a prefix appears once — unless its text is the lossy image of several (infdx2.h: lossy)
+            v.push_back((uint32_t)all.size()); all.push_back(List{r.p, (uint32_t)n, 0u});
             stored += (uint64_t)n; r.p += (size_t)n * 7; return true;
         };
         const int32_t n1 = r.get<int32_t>();
         if (!r.ok || n1 < 0 || n1 > 65536) return "the stored short-query index is malformed";
-        for (int32_t i = 0; i < n1; i++) { const u16 c = r.get<uint16_t>(); if (!r.ok || !take(keyOf(&c, 1))) return "the stored short-query index is malformed"; }
+        for (int32_t i = 0; i < n1; i++) { const u16 c = r.get<uint16_t>(); if (!r.ok || !take(keyOf(&c, 1), false)) return "the stored short-query index is malformed"; }
         const int32_t nm = r.get<int32_t>();
         if (!r.ok || nm < 0 || (size_t)nm > (r.n - r.p) / 5) return "the stored short-query index is malformed";
         std::u16string pf;
         for (int32_t i = 0; i < nm; i++) {
-            if (!rd_string(r, pf) || pf.size() < 2 || pf.size() > 3 || !take(keyOf((const u16*)pf.data(), (int)pf.size()))) return "the stored short-query index is malformed";
+            if (!rd_string(r, pf) || pf.size() < 2 || pf.size() > 3) return "the stored short-query index is malformed";
+            bool rep = false; for (char16_t c : pf) if (c == 0xFFFD) rep = true;
+            if (!take(keyOf((const u16*)pf.data(), (int)pf.size()), rep)) return "the stored short-query index is malformed";
         }
         // regenerate: tokens of the index text in order, prefixes of 1..3 characters, position = (ushort) token index (PositionalPrefixIndex.cs:56-118)
         std::vector<std::pair<uint64_t, uint16_t>> want;
         uint64_t made = 0;
+        std::unordered_map<uint64_t, uint32_t> listOf;                      // regenerated prefix -> its stored list, fixed at the prefix's first appearance
+        std::unordered_map<uint64_t, uint32_t> nextUnder;                   // stored text -> how many of its lists are taken
+        auto list_for = [&](uint64_t key) -> int64_t {
+            auto f = listOf.find(key);
+            if (f != listOf.end()) return f->second;
+            const int L = (int)(key >> 48); u16 u[3]; for (int i = 0; i < L; i++) u[i] = (u16)(key >> (16 * i));
+            uint64_t sk = key;
+            if (L >= 2 && has_lone_surrogate(u, (size_t)L)) { const std::u16string ls = lossy(u, (size_t)L); sk = keyOf(ls.data(), L); }      // single characters are written as numbers
+            auto v = byKey.find(sk);
+            if (v == byKey.end()) return -1;
+            uint32_t& nx = nextUnder[sk];
+            if (nx >= v->second.size()) return -1;
+            const uint32_t li = v->second[nx++];
+            listOf.emplace(key, li); return li;
+        };
         for (int32_t d = 0; d < N; d++) {
             const uview t(ix.text.data() + ix.textOff[d], (size_t)(ix.textOff[d + 1] - ix.textOff[d]));
             want.clear(); uint32_t tok = 0;
             for_each_word(t, [&](int off, int len) { const int mx = std::min(len, 3); for (int L = 1; L <= mx; L++) want.push_back({keyOf(t.data() + off, L), (uint16_t)tok}); tok++; });
+            // lists are fixed in order of first appearance (token order), the entries of a document are then matched per list in position order
+            for (auto& w : want) if (list_for(w.first) < 0) return "the stored short-query index lacks a (prefix, document, position) entry of the index texts";
             std::sort(want.begin(), want.end());
             for (auto& w : want) {
-                auto it = lists.find(w.first);
-                if (it == lists.end() || it->second.cur >= it->second.n) return "the stored short-query index lacks a (prefix, document, position) entry of the index texts";
-                const uint8_t* e = F.blob.data() + it->second.at + (size_t)it->second.cur++ * 7;
+                List& Lst = all[(size_t)list_for(w.first)];
+                if (Lst.cur >= Lst.n) return "the stored short-query index lacks a (prefix, document, position) entry of the index texts";
+                const uint8_t* e = F.blob.data() + Lst.at + (size_t)Lst.cur++ * 7;
                 int32_t doc; uint16_t pos; std::memcpy(&doc, e, 4); std::memcpy(&pos, e + 4, 2);
                 if (doc != d || pos != w.second || e[6] != 1) return "a posting of the stored short-query index differs from the index texts";
             }
@@ -182,7 +235,9 @@ inline const char* check_derived(const File& F, const HostIndex& ix) {
             uint32_t tokens = 0; int fo = 0, fl = 0;
             for_each_word(text, [&](int off, int len) { if (tokens == 0) { fo = off; fl = len; } tokens++; });
             const uint16_t wantCount = (uint16_t)std::min<uint32_t>(tokens, 65535u);
-            if (count != wantCount || first.size() != (size_t)fl || (fl && std::memcmp(first.data(), text.data() + fo, (size_t)fl * 2) != 0))
+            const bool sameFirst = first.size() == (size_t)fl && (fl == 0 || std::memcmp(first.data(), text.data() + fo, (size_t)fl * 2) == 0 ||
+                                                                    (has_lone_surrogate(text.data() + fo, (size_t)fl) && lossy(text.data() + fo, (size_t)fl) == first));
+            if (count != wantCount || !sameFirst)
                 return "an entry of the stored document metadata cache differs from the stored document text";
         }
     }
@@ -200,15 +255,14 @@ inline const char* check_derived(const File& F, const HostIndex& ix) {
             const Csr& C = which ? ix.wmLd1 : ix.wmExact;
             const int32_t n = w.get<int32_t>();
             if (!w.ok || n < 0 || (size_t)n != C.K()) return which ? "the stored symmetric-delete dictionary holds another number of keys than the rebuilt one" : "the stored exact-word dictionary holds another number of keys than the rebuilt one";
-            std::vector<uint8_t> seen(C.K(), 0);
+            LossyMatcher M(C.keys);
             for (int32_t i = 0; i < n; i++) {
                 if (!rd_string(w, key)) return "the stored WordMatcher dictionaries are malformed";
                 const int32_t len = w.get<int32_t>();
                 docs.clear();
                 if (!w.ok || len < 0 || !rd_roaring(w, (size_t)len, N, docs)) return "a document set of the stored WordMatcher dictionaries is malformed";
-                const int64_t id = C.keys.find(uview((const u16*)key.data(), key.size()));
-                if (id < 0 || seen[(size_t)id]) return "a key of the stored WordMatcher dictionaries does not exist in the rebuilt one";
-                seen[(size_t)id] = 1;
+                const int64_t id = M.match(key);
+                if (id < 0) return "a key of the stored WordMatcher dictionaries does not exist in the rebuilt one";
                 const uint64_t b = C.off[(size_t)id], m = C.off[(size_t)id + 1] - b;
                 if (m != docs.size() || !std::equal(docs.begin(), docs.end(), C.doc.begin() + (ptrdiff_t)b)) return "a document set of the stored WordMatcher dictionaries differs from the rebuilt one";
             }

@@ -34,8 +34,30 @@ def checksum_bytes(data: bytes):
     return c
 
 
+def _units(s: str):
+    """UTF-16 code units of a Python string (which may hold half a surrogate pair as a code point of its own)."""
+    raw = s.encode("utf-16-le", "surrogatepass")
+    return struct.unpack("<%dH" % (len(raw) // 2), raw)
+
+
+def _from_units(units) -> str:
+    return struct.pack("<%dH" % len(units), *units).decode("utf-16-le", "surrogatepass")
+
+
+def lossy(s: str) -> str:
+    """What Encoding.UTF8 (replacement fallback) makes of a .NET string: half a surrogate pair on its own becomes U+FFFD."""
+    u = _units(s); out = []; i = 0
+    while i < len(u):
+        c = u[i]
+        if 0xD800 <= c <= 0xDBFF and i + 1 < len(u) and 0xDC00 <= u[i + 1] <= 0xDFFF:
+            out += [c, u[i + 1]]; i += 2
+        else:
+            out.append(0xFFFD if 0xD800 <= c <= 0xDFFF else c); i += 1
+    return struct.pack("<%dH" % len(out), *out).decode("utf-16-le")
+
+
 def _string(s: str) -> bytes:        # BinaryWriter.Write(string): 7-bit encoded UTF-8 byte length + bytes
-    b = s.encode("utf-8"); n = len(b); out = bytearray()
+    b = lossy(s).encode("utf-8"); n = len(b); out = bytearray()
     while True:
         if n >= 0x80:
             out.append((n & 0x7F) | 0x80); n >>= 7
@@ -76,14 +98,14 @@ def words_of(text):
 
 
 def _u16len(s):
-    return len(s.encode("utf-16-le")) // 2
+    return len(s.encode("utf-16-le", "surrogatepass")) // 2
 
 
 def _compact_trie(pairs, reverse=False):
     """FstBuilder.AddToTrie / AddReversed (the last output of a repeated word wins) + CompactTrie (BFS, children ordered by label).  Labels are UTF-16 units."""
     root = {"c": {}, "f": False, "o": -1}
     for w, o in pairs:
-        units = struct.unpack("<%dH" % _u16len(w), w.encode("utf-16-le"))
+        units = _units(w)
         cur = root
         for u in (reversed(units) if reverse else units):
             cur = cur["c"].setdefault(u, {"c": {}, "f": False, "o": -1})
@@ -121,7 +143,7 @@ def short_query_section(index_texts):
     single, multi = {}, {}
     for d, text in enumerate(index_texts):
         for k, tok in enumerate(words_of(text)):
-            units = struct.unpack("<%dH" % _u16len(tok), tok.encode("utf-16-le"))
+            units = _units(tok)
             for L in range(1, min(3, len(units)) + 1):
                 key = units[:L]
                 (single if L == 1 else multi).setdefault(key, []).append((d, k & 0xFFFF))
@@ -133,7 +155,7 @@ def short_query_section(index_texts):
         out += struct.pack("<H", key[0]) + plist(single[key])
     out += struct.pack("<i", len(multi))
     for key, ps in multi.items():
-        out += _string(struct.pack("<%dH" % len(key), *key).decode("utf-16-le", "surrogatepass")) + plist(ps)
+        out += _string(_from_units(key)) + plist(ps)
     return bytes(out)
 
 
@@ -180,13 +202,13 @@ def wordmatcher_section(wm_texts, min_exact=2, max_exact=8, min_ld1=3, max_ld1=8
     for d, text in enumerate(wm_texts):
         for w in words_of(text):
             n = _u16len(w)
-            units = struct.unpack("<%dH" % n, w.encode("utf-16-le"))
+            units = _units(w)
             if min_exact <= n <= max_exact:
                 add(exact, w, d)
             if min_ld1 <= n <= max_ld1:
                 for i in range(n):
                     v = units[:i] + units[i + 1:]
-                    add(ld1, struct.pack("<%dH" % len(v), *v).decode("utf-16-le", "surrogatepass"), d)
+                    add(ld1, _from_units(v), d)
             if n >= min_ld1:
                 occ.append((w, d))                 # _fstIndex is null while indexing: every occurrence gets a new id, the FST keeps the last (Q13)
     out = bytearray(b"\x01")

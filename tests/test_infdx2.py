@@ -12,7 +12,7 @@ from tests.test_oracle_kats import TEN_DOCS
 from tools.synth import Synth
 
 
-def _oracle_file(path, docs, corrupt=None, bump_weight=False, deleted=(), tamper=None):
+def _oracle_file(path, docs, corrupt=None, bump_weight=False, deleted=(), tamper=None, mutate_terms=None):
     o = O.OracleEngine.create_default(); o.index(docs)
     ex = o.export_index()
     terms = []
@@ -22,6 +22,8 @@ def _oracle_file(path, docs, corrupt=None, bump_weight=False, deleted=(), tamper
         a, b = int(ex["post_off"][t]), int(ex["post_off"][t + 1])
         post = list(zip(ex["post_doc"][a:b].tolist(), ex["post_w"][a:b].tolist()))
         terms.append((o.term_text(t), int(ex["df"][t]), post))
+    if mutate_terms is not None:
+        mutate_terms(terms)
     if bump_weight:
         text, df, post = terms[len(terms) // 2]; terms[len(terms) // 2] = (text, df, [(post[0][0], post[0][1] + 1)] + post[1:])
     # the derived sections as the reference derives them: term FST over EVERY term of the collection, short-query index, metadata cache, WordMatcher
@@ -168,6 +170,61 @@ def test_flipped_bytes_in_the_derived_sections_never_get_past_the_bounds_checks(
             assert ex.code in (1, 5); refused += 1
     print("refused", refused, "accepted", accepted)
     assert refused >= 396
+
+
+def test_reference_persistence_kats(tmp_path):
+    """PersistenceTests.cs:13-64 (SaveAndLoadIndex_PreservesData) and :152-196 (SaveAndLoadIndex_UnicodeSurrogateCharacters), as far as they reach this path:
+    the saved index of the two-document corpus answers "fox" -> [1], "dog" -> [2] (the oracle, as the reference asserts before AND after the round trip) and loads
+    with the vocabulary it was saved with; the index of the single document U+1F50D — whose first 3-gram ends in HALF the surrogate pair, which BinaryWriter writes
+    as U+FFFD — loads too (the reference's own Load accepts it), again with the same vocabulary.  The query of the second test is two UTF-16 units long: the
+    ShortQueryProcessor path, outside this hot path (the product flags it unsupported)."""
+    docs = [(1, "The quick brown fox"), (2, "jumps over the lazy dog")]
+    p = str(tmp_path / "test_index.bin")
+    o, nterms, _ = _oracle_file(p, docs)
+    assert o.search("fox", 10)["keys"] == [1] and o.search("dog", 10)["keys"] == [2]
+    e = SearchEngine.create_default(device=-1)
+    assert e.load_index(p)[:2] == (2, nterms) and e.index_stats()["terms"] == o.num_terms
+
+    docs = [(1, "\U0001F50D")]
+    p = str(tmp_path / "surrogates_index.bin")
+    o, nterms, _ = _oracle_file(p, docs)
+    assert nterms == 2 and any("\ufffd" in W.lossy(o.term_text(t)) for t in range(o.num_terms))      # the file really holds a replaced half pair
+    e = SearchEngine.create_default(device=-1)
+    assert e.load_index(p)[:2] == (1, 2) and e.index_stats()["terms"] == o.num_terms == 2
+
+
+ASTRAL_DOCS = [(1, "\U0001F50Dab zeta"), (2, "\U0001F50Eab yotta"), (3, "plain \U0001F50Dab"), (4, "x\U0001F50D \U0001F50Ex \U0001F50Dab"), (5, "\U0001F50D"),
+               (6, "\U00020000\U00020001 cjk\U00020001"), (7, "\ufffdab already replaced"), (8, "x\U00020000 end")]          # "x\ud83d" / "x\ud840": two token prefixes that are stored as "x\ufffd"
+
+
+def test_keys_cut_out_of_surrogate_pairs_are_matched_through_the_lossy_utf8(tmp_path):
+    """Characters outside the BMP: 3-gram windows, 1..3-unit token prefixes and single-unit deletions cut surrogate pairs apart, BinaryWriter stores the halves as
+    U+FFFD, and several different keys collapse onto one stored text ("\udd0dab" and "\udd0eab" -> "\ufffdab", next to a document that really holds "\ufffdab").
+    The reader matches them in their order of first appearance; the file loads, and it stops loading when two colliding terms swap their postings."""
+    p = str(tmp_path / "astral.infdx2")
+    o, nterms, npost = _oracle_file(p, ASTRAL_DOCS)
+    texts = [W.lossy(o.term_text(t)) for t in range(o.num_terms)]
+    assert len(set(texts)) < len(texts)                                # at least two terms share their stored text
+    e = SearchEngine.create_default(device=-1)
+    assert e.load_index(p) == (len(ASTRAL_DOCS), nterms, npost)
+
+    # swap the postings of two terms with the same stored text: the same bytes for the names, each other's lists under them
+    def swap(terms):
+        first = {}
+        for i, (text, df, post) in enumerate(terms):
+            x = W.lossy(text)
+            if x in first and (terms[first[x]][1], terms[first[x]][2]) != (df, post):
+                j = first[x]
+                terms[i], terms[j] = (terms[i][0], terms[j][1], terms[j][2]), (terms[j][0], df, post)
+                return
+            first.setdefault(x, i)
+        raise AssertionError("no two colliding terms with different postings in this corpus")
+    bad = str(tmp_path / "astral_bad.infdx2")
+    _oracle_file(bad, ASTRAL_DOCS, mutate_terms=swap)
+    e = SearchEngine.create_default(device=-1)
+    with pytest.raises(InfidexError) as ex:
+        e.load_index(bad)
+    assert ex.value.code == 5, str(ex.value)
 
 
 def test_roaring_bitmaps_of_every_container_kind(tmp_path):

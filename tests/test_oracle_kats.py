@@ -355,3 +355,19 @@ def test_deleted_documents_are_skipped_not_reindexed():
     r = o.search("qick fux", 10)["keys"]
     o.delete_keys(r[:1])
     assert o.search("qick fux", 10)["keys"] == r[1:]
+
+
+# ---- SynonymTests.cs:96-143 (search-level expectations; the reference builds these two engines with indexSizes [4, 5, 6] — the expectation tested is the
+#      synonym behaviour, which the default configuration must show as well: both spellings are canonicalised to one root at index and at query time) ----
+def test_synonyms_find_both_terms():  # :96-122
+    o = O.OracleEngine.create_default(); o.add_synonym("car", "automobile")
+    o.index([(1, "I drive a car to work"), (2, "This automobile is fast"), (3, "The truck is big")])
+    keys = o.search("car", 10)["keys"]
+    assert len(keys) >= 2 and {1, 2} <= set(keys)
+
+
+def test_synonyms_work_in_both_directions():  # :124-143
+    o = O.OracleEngine.create_default(); o.add_synonym("car", "automobile")
+    o.index([(1, "I drive a car to work"), (2, "This automobile is fast")])
+    keys = o.search("automobile", 10)["keys"]
+    assert len(keys) >= 2 and {1, 2} <= set(keys)
