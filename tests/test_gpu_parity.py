@@ -488,3 +488,20 @@ def test_expansion_cache_eviction_inside_a_batch():
         for x, y in zip(r, host[0]):
             assert np.array_equal(x, y)
     assert np.array_equal(host[0][0], k) and np.array_equal(host[0][3], c)
+
+
+def test_segmented_documents_on_gpu():
+    """SegmentTrackingTests.cs:92-210, 324-345: several documents under one DocumentKey.  One row per key (ConsolidateSegments), and — the part the reference's
+    assertions do not see but its code does — Stage 2 scores a key through GetDocumentByPublicKey, i.e. with the text of the key's FIRST document and the best
+    segment's BM25 share: keys AND scores equal the oracle's, for the reference's queries and for queries that hit several segments of one key."""
+    from tests.test_oracle_kats import SEGMENT_CASES
+    extra = {0: ["summary animals"], 1: ["chapter one", "batman robin"], 2: ["the dog"], 4: ["hero journey"], 5: ["segment text"]}
+    for i, (docs, q, want) in enumerate(SEGMENT_CASES):
+        o = O.OracleEngine.create_default(); o.index(docs)
+        e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+        queries = [q] + extra.get(i, [])
+        for text, r in zip(queries, e.search_batch(queries, 10)):
+            w = o.search(text, 10)
+            assert [x.document_id for x in r.records] == w["keys"], (text, r.records, w)
+            assert np.allclose([x.score for x in r.records], w["scores"], rtol=0, atol=FINAL_ATOL), (text, r.records, w)
+        assert sorted(x.document_id for x in e.search_batch([q], 10)[0].records) == want

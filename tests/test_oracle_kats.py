@@ -371,3 +371,26 @@ def test_synonyms_work_in_both_directions():  # :124-143
     o.index([(1, "I drive a car to work"), (2, "This automobile is fast")])
     keys = o.search("automobile", 10)["keys"]
     assert len(keys) >= 2 and {1, 2} <= set(keys)
+
+
+# ---- SegmentTrackingTests.cs:92-210, 324-345: several documents under one DocumentKey (segments) -> one row per key ------------------------------
+# (Document.SegmentNumber's index-time effect — continuation segments are tokenised without the start padding, Tokenizer.cs — is not restated: these
+#  expectations do not depend on it.  What they pin: ConsolidateSegments keeps one row per key, Stage 2 scores a key through GetDocumentByPublicKey.)
+SEGMENT_CASES = [
+    ([(1, "Introduction to the topic of animals"), (1, "The quick brown fox jumps over the lazy dog"), (1, "Conclusion and summary of findings")], "fox", [1]),          # :92-115
+    ([(1, "Introduction chapter one"), (1, "Batman fights crime in Gotham City"), (1, "Conclusion chapter one"), (2, "Batman and Robin save the day"),
+      (2, "The end of their adventure"), (3, "Superman flies faster than a speeding bullet")], "batman", [1, 2]),                                                      # :118-148
+    ([(1, "The cat sat on the mat"), (1, "The dog ran through the park"), (1, "The bird flew in the sky")], "batman", []),                                               # :151-166
+    ([(1, "The cat sat on the mat"), (2, "The dog ran through the park"), (3, "The bird flew in the sky")], "batman", []),                                               # :169-184
+    ([(1, "Chapter 1 introduction"), (1, "The hero begins his journey"), (2, "The hero saves the day"), (3, "A story about courage")], "hero", [1, 2]),                 # :187-211
+    ([(1, f"Segment {i} text content") if i != 5 else (1, "This segment contains batman") for i in range(10)], "batman", [1]),                                          # :324-345
+]
+
+
+@pytest.mark.parametrize("case", range(len(SEGMENT_CASES)))
+def test_segmented_documents_give_one_row_per_key(case):
+    docs, q, want = SEGMENT_CASES[case]
+    o = O.OracleEngine.create_default(); o.index(docs)
+    r = o.search(q, 10)
+    assert sorted(r["keys"]) == want and len(r["keys"]) == len(want)
+    assert all(s > 0 for s in r["scores"])
