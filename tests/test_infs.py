@@ -157,6 +157,35 @@ def test_corrupted_files_are_refused(tmp_path):
     assert os.path.getsize(p) == n
 
 
+def test_flipped_bits_never_get_past_the_bounds_checks(tmp_path):
+    """600 single-bit flips anywhere in a segment file: the reader refuses the file or — where the bit is one the format leaves free (a weight below its block's
+    maximum, slack of the Elias-Fano arrays) — reads it; it never crashes and never reads outside the file.  Whatever it reads satisfies the invariants the
+    export promises: ascending document ids below the document count in every list, term texts in ordinal order."""
+    rng = np.random.default_rng(5)
+    terms = [(f"w{i:03d}" + "x" * int(rng.integers(0, 4)), np.sort(rng.choice(200000, int(rng.integers(1, 900)), replace=False)).tolist(), None) for i in range(60)]
+    terms = sorted([(t, d, rng.integers(1, 255, len(d)).tolist()) for t, d, _ in terms])
+    raw = W.write(str(tmp_path / "base.seg"), terms, 200000)
+    refused = read = 0
+    q = str(tmp_path / "f.seg")
+    for k in range(600):
+        m = bytearray(raw)
+        at = int(rng.integers(0, len(raw)))
+        m[at] ^= 1 << int(rng.integers(0, 8))
+        open(q, "wb").write(bytes(m))
+        try:
+            dc, names, poff, docs, w = _read(q)
+        except InfidexError as ex:
+            assert ex.code == 1; refused += 1
+            continue
+        read += 1
+        assert names == sorted(names) and len(set(names)) == len(names)
+        for i in range(len(names)):
+            d = docs[int(poff[i]):int(poff[i + 1])]
+            assert d.size == 0 or (np.all(np.diff(d) > 0) and 0 <= d[0] and d[-1] < dc)
+    print("refused", refused, "read", read)
+    assert refused > 300
+
+
 @pytest.mark.gpu
 def test_a_verified_segment_is_the_index_the_gpu_searches(tmp_path):
     """Flush-style segments of a corpus (two flushes) verified against the GPU engine's index of the same documents; the segment's CSR, mapped from term ordinals to
