@@ -41,6 +41,8 @@ def _stale(target, deps):
 
 
 def _build(lib, obj_dev, obj_host, extra, force, verbose):
+    if not force and not _stale(lib, sources()):
+        return lib                                   # up to date, whether or not the intermediate objects travelled with the tree
     # each object is rebuilt only when one of ITS sources changed: a host-side change leaves the device object (the kernels) byte for byte as it was
     cmds = []
     if force or _stale(obj_dev, device_sources()):
