@@ -97,7 +97,7 @@ def load_library():
 
 
 def _u16(s: str) -> np.ndarray:
-    return np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16).copy()
+    return np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16).copy()
 
 
 def _p(a, ty):
@@ -473,4 +473,4 @@ def normalize(s, lower=False):
     L = load_library()
     x = _u16(s); out = np.zeros(len(x) + 8, np.uint16)
     n = L.infx_engine_normalize(_p(x, C.c_uint16), len(x), int(lower), _p(out, C.c_uint16), len(out))
-    return out[:n].tobytes().decode("utf-16-le")
+    return out[:n].tobytes().decode("utf-16-le", errors="surrogatepass")

@@ -44,7 +44,7 @@ def lib():
 
 def u16(s):
     """Python str -> (uint16 numpy array) of UTF-16 code units."""
-    return np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16).copy()
+    return np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16).copy()
 
 
 def _p(a, ty):
@@ -232,7 +232,7 @@ def lcs(a, b, tol):
 def normalize(s, lower=False):
     x = u16(s); out = np.zeros(len(x) + 8, np.uint16)
     n = lib().orc_normalize(_p(x, C.c_uint16), len(x), int(lower), _p(out, C.c_uint16), len(out))
-    return out[:n].tobytes().decode("utf-16-le")
+    return out[:n].tobytes().decode("utf-16-le", errors="surrogatepass")
 
 
 def coverage_standalone(query, doc, lcs_sum=0.0, bm25=0.0, word_idf=None):

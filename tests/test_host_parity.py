@@ -302,3 +302,33 @@ def test_expansion_cache_is_the_references_lru_1000():
         for k in a:
             assert np.array_equal(a[k], b[k]), k
     assert e.fuzzy_cache_size() == 1000
+
+
+def test_characters_outside_the_bmp_index_and_plan_like_the_oracle():
+    """UTF-16 is the reference's text model: 3-gram windows, token prefixes and single-unit deletions cut surrogate pairs apart, and a .NET string may even hold half
+    a pair on its own.  Index arrays, plans and WordMatcher sets of the product equal the oracle's on such texts."""
+    from infidex_amd import Document
+    from infidex_amd.engine import normalize as _norm
+    docs = [(1, "\U0001F50Dab zeta"), (2, "\U0001F50Eab yotta"), (3, "plain \U0001F50Dab"), (4, "x\U0001F50D \U0001F50Ex \U0001F50Dab"), (5, "\U0001F50D"),
+            (6, "\U00020000\U00020001 cjk\U00020001"), (7, "\ufffdab already replaced"), (8, "x\U00020000 end"), (20, "emoji \U0001F600\U0001F601 party \U0001F600"),
+            (21, "\U0001D49C\U0001D4B7\U0001D4B8 math script"), (22, "mixed a\U0001F50Db c\U0001F50Ed"), (23, "\ud83d lone high"), (24, "lone low \udd0d tail")]
+    prod = SearchEngine.create_default(device=-1, threads=2); prod.index_documents([Document(k, t) for k, t in docs])
+    orc = O.OracleEngine.create_default(); orc.index(docs)
+    a, b = prod.export_index(), orc.export_index()
+    assert prod.index_stats()["terms"] == orc.num_terms
+    for k in ("df", "post_off", "post_doc", "post_w", "doc_len"):
+        assert np.array_equal(a[k], b[k]), k
+    for t in range(orc.num_terms):
+        assert prod.term_text(t) == orc.term_text(t)
+    planned = 0
+    for q in ["\U0001F50Dab", "\U0001F50Eab zeta", "a\U0001F50Db", "emoji \U0001F600", "\U0001D49C\U0001D4B7\U0001D4B8", "x\U0001F50D", "\U0001F50Dxb", "cjk\U00020001",
+              "party \U0001F601\U0001F600", "\U0001F50Dab\U0001F50E", "\ud83d lone", "low \udd0d", "\U0001F50D"]:
+        p = prod.plan(q); r = orc.search(q, 10)
+        if r["unsupported"]:
+            assert p["flags"] & 2, q
+            continue
+        t, df, idf, mx = orc.last_terms()
+        assert np.array_equal(p["term_ids"], t) and np.array_equal(p["df"], df) and np.array_equal(p["idf"], idf), q
+        assert np.array_equal(prod.wordmatcher(q), orc.wordmatcher(_norm(q, lower=True))), q
+        planned += 1
+    assert planned >= 10
