@@ -30,6 +30,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>          // types and enums only: the functions are resolved with dlopen (rccl_api)
 #include "../../include/infidex_hip.h"
+#include "unicode_tables.h"        // generated: BMP simple case mappings, letter set (tools/gen_unicode_tables.py)
 
 #define WAVE 64
 #define FILT_MAXCOL 64
@@ -294,6 +295,7 @@ struct infx_stream {
     unsigned long long* arMask = nullptr; size_t arMaskCap = 0; int maskWords = 0;     // per-row hit masks of the last accumulate launch
     uint32_t* arExc = nullptr; uint32_t* exCand = nullptr; infx_hit* exOut = nullptr; size_t exCap = 0;       // tf exception records, candidate lists, replay rows (arena-sized)
     void* exChunks = nullptr; size_t capExChunks = 0; void* exQueries = nullptr; size_t capExQueries = 0; void* exTasks = nullptr; size_t capExTasks = 0; uint32_t* exCounters = nullptr;
+    void* exContEnd = nullptr; size_t capExContEnd = 0;      // k_ex_cand: candidates up to the end of every (query, container)
     uint32_t exChunkCap = 0; size_t arBound = 0;
     void* dDir = nullptr; size_t capDir = 0;
     void* dRefTerms = nullptr; size_t capRefTerms = 0; void* dExactFlag = nullptr; size_t capExactFlag = 0; uint32_t* dExactStat = nullptr;   // k_exact1 inputs
@@ -306,6 +308,7 @@ struct infx_stream {
     uint64_t lastAlgBytes = 0, lastCandTotal = 0;
     bool timedAcc = false, timedSel = false, timedCov = false;
     void* dStats = nullptr;      // k_accumulate profiling counters (INFX_ACC_SKIP=8)
+    void* dExProf = nullptr; size_t capExProf = 0;      // INFX_EXACT_PROF: per-query cycle counters of the replay kernels (EXP_WORDS u64 per query)
     // exact replay across document shards (exactsh.hip.inc)
     void *dNext = nullptr, *dPrior = nullptr, *shBlob = nullptr, *dAllBlobs = nullptr, *dAllNext = nullptr, *dChainState = nullptr, *dChainNeed = nullptr;
     size_t capNext = 0, capPrior = 0, capShBlob = 0, capAllBlobs = 0, capAllNext = 0, capChainState = 0, capChainNeed = 0;
@@ -605,6 +608,13 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
 // k_exact1 behind k_select: unsharded indexes only (the reference's chunking follows GLOBAL 65 536-id containers and its heap is sequential
 // over the whole corpus; document shards keep k_select's deterministic (score, doc id) cut)
 static bool exact_slow_only() { static const bool v = [] { const char* e = getenv("INFX_EXACT_SLOW"); return e && e[0] == '1'; }(); return v; }
+// the full heap of the replay lives in registers (RHeap, exact3.hip.inc) when its entries fit the packing: internal ids below 2^30, depth <= 512;
+// INFX_EX_HEAP_LDS=1 keeps the LDS heap (A/B measurements, parity tooling)
+static int ex_heap_in_regs(const infx_index* ix, int depth) {
+    static const bool off = [] { const char* e = getenv("INFX_EX_HEAP_LDS"); return e && e[0] == '1'; }();
+    const long long total = std::max<long long>(ix->d.totalDocs, (long long)ix->d.docBase + ix->d.N);
+    return (!off && depth <= EXS_MAXDEPTH && total < (1ll << 30)) ? 1 : 0;
+}
 static bool exact_possible(infx_stream* s) { return exact_enabled(s->ix) && s->maskWords > 0 && s->ix->nranks == 1 && s->ix->d.docBase == 0; }
 // chunk table of the parallel replay: every query needs at most (containers + reserved rows / 4096 + 2) entries
 static int32_t exact_chunk_tables(infx_stream* s, uint32_t nq, ExBufs& xb) {
@@ -613,11 +623,34 @@ static int32_t exact_chunk_tables(infx_stream* s, uint32_t nq, ExBufs& xb) {
     const size_t cap = (size_t)nq * (nCont + 2) + s->arBound / EX_CHUNK + 16;
     if (cap > 0x7FFFFFF0ull) return fail(INFX_ECAPACITY, "exact-replay chunk table too large; split the batch%s");
     GROW(s->exChunks, s->capExChunks, cap * sizeof(ExChunk));
-    GROW(s->exTasks, s->capExTasks, cap * 2 * 4);
+    GROW(s->exTasks, s->capExTasks, cap * 3 * 4);
     GROW(s->exQueries, s->capExQueries, (size_t)nq * sizeof(ExQuery));
+    GROW(s->exContEnd, s->capExContEnd, (size_t)nq * nCont * 4);
     s->exChunkCap = (uint32_t)cap;
-    HIPCHK(hipMemsetAsync(s->exCounters, 0, 16, s->st));
-    xb = ExBufs{s->exCand, s->exOut, s->arExc, (ExChunk*)s->exChunks, s->exChunkCap, (ExQuery*)s->exQueries, s->exCounters, (uint32_t*)s->exTasks, (uint32_t*)s->exTasks + cap};
+    HIPCHK(hipMemsetAsync(s->exCounters, 0, 32, s->st));
+    xb = ExBufs{s->exCand, s->exOut, s->arExc, (ExChunk*)s->exChunks, s->exChunkCap, (ExQuery*)s->exQueries, s->exCounters, (uint32_t*)s->exTasks, (uint32_t*)s->exTasks + cap,
+                (uint32_t*)s->exTasks + 2 * cap, (uint32_t*)s->exContEnd, nullptr, nullptr};
+    return INFX_OK;
+}
+// The scan and the chunk pass of the parallel replay on stream `st` (k_ex_cand, k_ex_theta, k_ex_chunk<1|4|16>).  With an auxiliary stream the two
+// workgroup variants of k_ex_chunk run beside the one-wave variant (disjoint chunks; each launch ends in a tail of a few long tasks).
+static int32_t launch_scan_and_chunks(infx_stream* s, uint32_t nq, Arena ar, ExBufs xb, const float* prior, bool useAux) {
+    infx_index* ix = s->ix;
+    const int rpc = 65536 / ix->d.R, nCont = (ix->d.nRanges + rpc - 1) / rpc;
+    if (nCont > 65535) return fail(INFX_ECAPACITY, "exact replay: more than 65535 containers of 65536 documents in one shard%s");
+    k_ex_walk<false><<<dim3(nq, nCont), EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag, xb, nCont);
+    k_ex_prefix<<<nq, EXS_THREADS, 0, s->st>>>((const uint32_t*)s->dExactFlag, xb, nCont);
+    k_ex_walk<true><<<dim3(nq, nCont), EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag, xb, nCont);
+    k_ex_theta<<<nq, WAVE, 0, s->st>>>(ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, prior, nCont);
+    HIPCHK(hipEventRecord(s->evXa, s->st));
+    hipStream_t bigSt = s->st;
+    if (useAux && s->stAux && s->st == s->stMain) { HIPCHK(hipStreamWaitEvent(s->stAux, s->evXa, 0)); bigSt = s->stAux; }
+    k_ex_chunk<16><<<EXP_GRID16, 16 * WAVE, 0, bigSt>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 4, ix->avgdl);
+    k_ex_chunk<4><<<EXP_GRID4, 4 * WAVE, 0, bigSt>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksMid, 2, ix->avgdl);
+    if (bigSt != s->st) HIPCHK(hipEventRecord(s->evJoin, bigSt));
+    k_ex_chunk<1><<<EXP_GRID1, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksSmall, 1, ix->avgdl);
+    if (bigSt != s->st) HIPCHK(hipStreamWaitEvent(s->st, s->evJoin, 0));
+    HIPCHK(hipGetLastError());
     return INFX_OK;
 }
 static int32_t exact1_lds_ready(infx_index* ix, int MW, size_t* ldsOut) {
@@ -640,25 +673,40 @@ static int32_t enqueue_exact(infx_stream* s, uint32_t nq, int stride) {
     const bool fast = !slowOnly && depthCap <= EXS_MAXDEPTH;
     if (fast) {
         ExBufs xb; { int32_t rc_ = exact_chunk_tables(s, nq, xb); if (rc_) return rc_; }
-        k_ex_scan<<<nq, EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, nullptr);
-        HIPCHK(hipEventRecord(s->evXa, s->st));
-        // the chunks of <= 16 tiles and the longer ones come from two task lists and write disjoint rows: the second launch runs beside the first on the
-        // stream's auxiliary stream (each ends in a tail of a few long chunks: one after the other cost 2.1 + 1.6 ms)
-        hipStream_t bigSt = s->st;
-        if (s->stAux && s->st == s->stMain) { HIPCHK(hipStreamWaitEvent(s->stAux, s->evXa, 0)); bigSt = s->stAux; }
-        k_ex_chunk<EXC_BIG><<<2048, WAVE, 0, bigSt>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 2, ix->avgdl);
-        if (bigSt != s->st) HIPCHK(hipEventRecord(s->evJoin, bigSt));
-        k_ex_chunk<EXC_SMALL><<<8192, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksSmall, 1, ix->avgdl);
-        if (bigSt != s->st) HIPCHK(hipStreamWaitEvent(s->st, s->evJoin, 0));
+        static const bool exProf = getenv("INFX_EXACT_PROF") != nullptr;     // per-query cycle counters of the replay kernels (profiling only)
+        if (exProf) { GROW(s->dExProf, s->capExProf, ((size_t)nq * EXP_WORDS + (EXP_GRID1 + EXP_GRID4 + EXP_GRID16) * 4) * 8); HIPCHK(hipMemsetAsync(s->dExProf, 0, ((size_t)nq * EXP_WORDS + (EXP_GRID1 + EXP_GRID4 + EXP_GRID16) * 4) * 8, s->st)); }
+        xb.prof = exProf ? (unsigned long long*)s->dExProf : nullptr; xb.profChunk = exProf ? (unsigned long long*)s->dExProf + (size_t)nq * EXP_WORDS : nullptr;
+        { int32_t rc_ = launch_scan_and_chunks(s, nq, ar, xb, nullptr, true); if (rc_) return rc_; }
         HIPCHK(hipEventRecord(s->evXb, s->st));
-        static const bool exProf = getenv("INFX_EXACT_PROF") != nullptr;     // k_ex_heap counters (profiling only)
         k_ex_heap<<<nq, WAVE, 0, s->st>>>(ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, s->dExactStat,
-                                          exProf ? (unsigned long long*)s->dStats : nullptr);
+                                          exProf ? (unsigned long long*)s->dExProf : nullptr, ex_heap_in_regs(ix, depthCap));
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->evXc, s->st)); s->timedReplayParts = true;
-        if (exProf) { unsigned long long h[8]; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 64, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 64);
-            if (h[0]) fprintf(stderr, "[infx] k_ex_heap per query over %llu queries: chunks %.0f rows %.0f admitted-or-tested %.0f heap-cycles %.0f total-cycles %.0f\n", h[0],
-                              (double)h[5] / h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0]); }
+        if (exProf) {       // profiling only: per-query counters of the replay kernels -> mean / p50 / p90 / max and the slowest queries
+            hipStreamSynchronize(s->st);
+            std::vector<unsigned long long> h((size_t)nq * EXP_WORDS); hipMemcpy(h.data(), s->dExProf, h.size() * 8, hipMemcpyDeviceToHost);
+            uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipMemcpy(cnt, s->exCounters, 32, hipMemcpyDeviceToHost);
+            static const char* names[EXP_WORDS] = {"heap.cycles", "heap.heap_cycles", "heap.rows", "heap.ops", "heap.chunks", "scan.cycles", "theta.insert_cycles", "theta.inserts", "cand.batches", "cand.rows", "cand.cands",
+                                                   "theta.cycles", "-", "-", "-", "-"};
+            std::vector<uint32_t> qs; for (uint32_t q = 0; q < nq; q++) if (h[(size_t)q * EXP_WORDS + 0] || h[(size_t)q * EXP_WORDS + 5]) qs.push_back(q);
+            fprintf(stderr, "[infx] exact replay profile: %zu replayed queries of %u; chunk tasks 1-wave %u 4-wave %u 16-wave %u (chunk slots reserved %u)\n", qs.size(), nq, cnt[1], cnt[2], cnt[4], cnt[0]);
+            if (!qs.empty()) for (int w = 0; w < 12; w++) {
+                std::vector<unsigned long long> v; for (uint32_t q : qs) v.push_back(h[(size_t)q * EXP_WORDS + w]);
+                std::sort(v.begin(), v.end()); double sum = 0; for (auto x : v) sum += (double)x;
+                fprintf(stderr, "[infx]   %-20s mean %12.0f  p50 %12llu  p90 %12llu  p99 %12llu  max %12llu\n", names[w], sum / v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back());
+            }
+            for (int which : {0, 5}) {
+                std::sort(qs.begin(), qs.end(), [&](uint32_t a, uint32_t b) { return h[(size_t)a * EXP_WORDS + which] > h[(size_t)b * EXP_WORDS + which]; });
+                for (size_t i = 0; i < std::min<size_t>(3, qs.size()); i++) { fprintf(stderr, "[infx]   slowest by %s: q %u:", names[which], qs[i]); for (int w = 0; w < 13; w++) fprintf(stderr, " %llu", h[(size_t)qs[i] * EXP_WORDS + w]); fprintf(stderr, "\n"); }
+            }
+            std::vector<unsigned long long> ck((EXP_GRID1 + EXP_GRID4 + EXP_GRID16) * 4); hipMemcpy(ck.data(), (char*)s->dExProf + (size_t)nq * EXP_WORDS * 8, ck.size() * 8, hipMemcpyDeviceToHost);
+            const int g0[4] = {0, EXP_GRID1, EXP_GRID1 + EXP_GRID4, EXP_GRID1 + EXP_GRID4 + EXP_GRID16};
+            for (int w = 0; w < 3; w++) {
+                unsigned long long n = 0, cy = 0, mx = 0, tl = 0, wgMax = 0;
+                for (int b = g0[w]; b < g0[w + 1]; b++) { n += ck[b * 4]; cy += ck[b * 4 + 1]; mx = std::max(mx, ck[b * 4 + 2]); tl += ck[b * 4 + 3]; wgMax = std::max(wgMax, ck[b * 4 + 1]); }
+                fprintf(stderr, "[infx]   k_ex_chunk<%d>: %llu tasks, cycles per task mean %.0f max %llu, busiest workgroup %llu cycles, tiles mean %.1f\n", w == 0 ? 1 : (w == 1 ? 4 : 16), n, n ? (double)cy / n : 0.0, mx, wgMax, n ? (double)tl / n : 0.0);
+            }
+        }
     }
     k_exact1<<<nq, EX_THREADS, lds1, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag,
                                              fast ? 2u : 1u, ix->avgdl, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, stride, depthCap, s->dExactStat, nullptr, nullptr);
@@ -1010,7 +1058,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
     HIPCHK(hipMalloc((void**)&s->dStats, 64)); HIPCHK(hipMemset(s->dStats, 0, 64));
     HIPCHK(hipMalloc((void**)&s->dExactStat, 32)); HIPCHK(hipMemset(s->dExactStat, 0, 32));      // [0..3] replay outcome counters, [4..7] k_select flag reasons
-    HIPCHK(hipMalloc((void**)&s->exCounters, 16)); HIPCHK(hipMemset(s->exCounters, 0, 16));
+    HIPCHK(hipMalloc((void**)&s->exCounters, 32)); HIPCHK(hipMemset(s->exCounters, 0, 32));
     *out = s; return INFX_OK;
 }
 void infx_stream_destroy(infx_stream* s) {
@@ -1018,7 +1066,7 @@ void infx_stream_destroy(infx_stream* s) {
     hipSetDevice(s->ix->cfg.device);
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
-                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters,
+                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters, s->exContEnd, s->dExProf,
                   s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount, s->dDense};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
@@ -1795,9 +1843,7 @@ int32_t infx_shard_replay_local(infx_stream* s, int32_t nshards, uint32_t nd, co
     if (possible) {
         Arena ar = make_arena(s);
         { int32_t rc_ = exact_chunk_tables(s, nd, xb); if (rc_) return rc_; }
-        k_ex_scan<<<nd, EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, ix->d.docBase > 0 ? (const float*)s->dPrior : nullptr);
-        k_ex_chunk<EXC_SMALL><<<8192, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksSmall, 1, ix->avgdl);
-        k_ex_chunk<EXC_BIG><<<2048, WAVE, 0, s->st>>>(ix->d, (const DevQuery*)s->dQueries, (const DevRefTerm*)s->dRefTerms, ar, xb, xb.tasksBig, 2, ix->avgdl);
+        { int32_t rc_ = launch_scan_and_chunks(s, nd, ar, xb, ix->d.docBase > 0 ? (const float*)s->dPrior : nullptr, false); if (rc_) return rc_; }
         // worst case: every reserved row of every flagged query is emitted
         const size_t need = shx_blob_bytes(nd, s->exChunkCap, 0) + s->exCap * sizeof(infx_hit);
         GROW(s->shBlob, s->capShBlob, need);
@@ -1845,7 +1891,7 @@ int32_t infx_shard_replay_merge(infx_stream* s, int32_t nshards, uint32_t nd, co
     UPX(s->dAllBlobs, all_blobs, (size_t)nshards * padded_bytes);
     HIPCHK(hipMemsetAsync(s->dExactStat, 0, 16, s->st));
     k_ex_heap_sh<<<nd, WAVE, 0, s->st>>>(nshards, ix->rank, nd, (const unsigned char*)s->dAllBlobs, (size_t)padded_bytes, (const uint32_t*)s->dExactFlag, depth,
-                                         exact_slow_only() ? 1 : 0, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, s->dExactStat);
+                                         exact_slow_only() ? 1 : 0, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, s->dExactStat, ex_heap_in_regs(ix, depth));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evX1, s->st)); s->timedReplay = true;
     DOWNX(hits_out, s->dHits, (size_t)nd * depth * sizeof(infx_hit));
