@@ -98,6 +98,22 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
+    # --gpus N is the number of ranks.  Started bare (no WORLD_SIZE: `python bench.py --gpus N`), the script launches itself under torch.distributed.run with
+    # one rank per GPU — the form the driver uses for N > 1 — and relays the ranks' output; started BY torch.distributed.run it checks that the launcher's
+    # world size is the one asked for, so a line can never report another N than the one it ran on.
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29533")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", port,
+               os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and os.environ.get("INFX_FORCE_SHARDED") != "1":
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} ranks; start `python bench.py --gpus N` "
+                 f"(it launches the ranks itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+
     # stdout carries ONE line, the result: everything else a library prints there (RCCL's start-up banner, C stdio) goes to stderr
     sys.stdout.flush()
     result_fd = os.dup(1)
@@ -115,12 +131,23 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("INFX_DIST_BACKEND", "nccl")     # "gloo" lets two ranks share one GPU when testing the sharded flow
         local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available() or backend == "nccl":       # (the launch-only CPU test runs over gloo without a device)
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist_mod.init_process_group(backend)
         dist = dist_mod
+    if os.environ.get("INFX_BENCH_LAUNCH_ONLY") == "1":      # tests/test_bench_launch.py: the launch path alone (ranks, process group, one collective), no GPU work
+        n = 1
+        if dist is not None:
+            import torch
+            t = torch.ones(1, device="cuda" if dist.get_backend() == "nccl" else "cpu"); dist.all_reduce(t); n = int(t.item())
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"launch_only": True, "n_gpus": world, "ranks_in_all_reduce": n, "gpus_arg": args.gpus}) + "\n").encode())
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     from tools.synth import Synth, CONFIGS
     from infidex_amd import SearchEngine, Session, build as _build
     _build.build()

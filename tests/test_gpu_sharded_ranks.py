@@ -68,3 +68,22 @@ def test_two_ranks_equal_the_oracle(tmp_path):
     print("2 ranks vs oracle:", same, "identical order,", flips, "near-tie flips")
     assert np.array_equal(r["cs"], c) and np.array_equal(r["ks"], k)                      # search_packed == search_stream
     assert np.array_equal(r["k1"], k[:100]) and np.array_equal(r["c1"], c[:100]) and np.array_equal(r["k2"], k[100:]) and np.array_equal(r["c2"], c[100:])
+
+
+def test_bench_gpus_2():
+    """`python bench.py --gpus 2` — started bare, as the driver starts it — runs the document-sharded bench on TWO ranks (gloo here: two ranks cannot share
+    one GPU under RCCL) and reports n_gpus == 2 with the same collectives issued on both ranks."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.update({"INFX_DIST_BACKEND": "gloo", "MASTER_PORT": "29641", "INFX_THREADS": "4"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--docs", "140000", "--steps", "2", "--warmup", "1", "--batch", "200", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    cs = d["collectives_per_rank"]
+    assert len(cs) == 2 and cs[0] == cs[1], cs
