@@ -539,7 +539,7 @@ inline int32_t prepare_cov_query(const HostIndex& ix, uview query, infx_cov_quer
     for_each_word(query, [&](int off, int len) { fus.push_back({off, len}); if (len >= 2) raw.push_back({off, len}); });
     for (auto& t : raw) {
         bool dup = false;
-        for (auto& u : uq) if (u.len == t.len && query.substr(u.off, u.len) == query.substr(t.off, t.len)) { dup = true; break; }
+        for (auto& u : uq) if (ic_equal(query.substr(u.off, u.len), query.substr(t.off, t.len))) { dup = true; break; }      // CoverageTokenizer.cs:50-57: OrdinalIgnoreCase
         if (!dup) uq.push_back(t);
     }
     if ((int)uq.size() > INFX_MAX_QUERY_TOKENS || (int)fus.size() > 2 * INFX_MAX_QUERY_TOKENS) return INFX_EUNSUPPORTED;

@@ -2,13 +2,15 @@
 // Mirrors, for the hot path only:
 //   Tokenization/TextNormalizer.cs:120-200, 203-304   Normalize + default diacritic map
 //   Tokenization/TokenizerSetup.cs:36-43              delimiters
-//   string.ToLowerInvariant (simple 1:1 case mapping; table-driven, ASCII + Latin-1 + Latin Ext-A + Greek/Cyrillic)
+//   string.ToLowerInvariant / char.IsLetter / OrdinalIgnoreCase: the BMP simple case mappings and the letter set, generated FROM DATA
+//   (../unicode_tables.h, tools/gen_unicode_tables.py: Unicode 13 simple mappings with .NET's invariant exceptions for U+0130 / U+0131)
 // Table-driven: one 64 Ki-entry fold table per operation, built once.
 #pragma once
 #include <cstdint>
 #include <string>
 #include <vector>
 #include <string_view>
+#include "../unicode_tables.h"
 
 namespace infx {
 
@@ -20,16 +22,15 @@ struct TextTables {
     std::vector<u16> lower;      // ToLowerInvariant
     std::vector<u16> norm;       // TextNormalizer char map (+ \t \n \r -> ' ')
     std::vector<uint8_t> delim;  // tokenizer delimiters
-    TextTables() : lower(65536), norm(65536), delim(65536, 0) {
+    std::vector<u16> icrep;      // OrdinalIgnoreCase on LOWER-cased text: lower-case characters that share their upper-case image with another one
+                                 // (final sigma / sigma, long s / s, micro sign / mu ...) -> the class representative lower(upper(c))
+    TextTables() : lower(65536), norm(65536), delim(65536, 0), icrep(65536) {
         for (int i = 0; i < 65536; i++) { lower[i] = (u16)i; norm[i] = (u16)i; }
-        for (int c = 'A'; c <= 'Z'; c++) lower[c] = (u16)(c + 32);
-        for (int c = 0xC0; c <= 0xDE; c++) if (c != 0xD7) lower[c] = (u16)(c + 32);
-        auto pairEvenUp = [&](int a, int b) { for (int c = a; c <= b; c += 2) lower[c] = (u16)(c + 1); };
-        pairEvenUp(0x100, 0x12E); pairEvenUp(0x132, 0x136); pairEvenUp(0x139, 0x147); pairEvenUp(0x14A, 0x176); pairEvenUp(0x179, 0x17D);
-        lower[0x178] = 0xFF;
-        for (int c = 0x391; c <= 0x3A9; c++) if (c != 0x3A2) lower[c] = (u16)(c + 32);
-        for (int c = 0x410; c <= 0x42F; c++) lower[c] = (u16)(c + 32);
-        for (int c = 0x400; c <= 0x40F; c++) lower[c] = (u16)(c + 80);
+        static const uint16_t lowerPairs[][2] = { INFX_UC_LOWER_PAIRS };
+        for (auto& pr : lowerPairs) lower[pr[0]] = pr[1];
+        static const uint16_t repPairs[][2] = { INFX_UC_ICREP_PAIRS };
+        for (int i = 0; i < 65536; i++) icrep[i] = (u16)i;
+        for (auto& pr : repPairs) icrep[pr[0]] = pr[1];
         static const char16_t* from = u"ÆæØøÅåÄäÖöÜüßŠšČčŘřŽžŇňŤťĎďĚěÁáÉéÍíÓóÚúÝýŮůĄąĆćĘęŁłŃńŚśŹźŻżŐőŰűĂăÂâÎîȘșȚțĞğİıŞşÀàÇçÈèÊêËëÌìÏïÑñÒòÔôÕõÙùÛûŸÿÐðÞþ";
         static const char16_t* to   = u"EeOoAaAaOoUusSsCcRrZzNnTtDdEeAaEeIiOoUuYyUuAaCcEeLlNnSsZzZzOoUuAaAaIiSsTtGgIiSsAaCcEeEeEeIiIiNnOoOoOoUuUuYyDdTt";
         for (int i = 0; from[i]; i++) norm[from[i]] = to[i];
@@ -54,6 +55,13 @@ inline void normalize_into(uview in, ustr& out) {
 }
 inline ustr normalize(uview in) { ustr o; normalize_into(in, o); return o; }
 inline void lower_inplace(ustr& s) { const auto& T = tables(); for (auto& c : s) c = T.lower[c]; }
+// string.Equals(a, b, OrdinalIgnoreCase) for lower-cased a and b (ToUpperInvariant images compared, char by char)
+inline bool ic_equal(uview a, uview b) {
+    if (a.size() != b.size()) return false;
+    const auto& T = tables();
+    for (size_t i = 0; i < a.size(); i++) if (a[i] != b[i] && T.icrep[a[i]] != T.icrep[b[i]]) return false;
+    return true;
+}
 inline bool is_ws(u16 c) {
     return c == 0x20 || (c >= 0x09 && c <= 0x0D) || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) ||
            c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;

@@ -5,13 +5,14 @@
 //   Tokenization/TextNormalizer.cs:120-200,203-304  (Normalize, default char map)
 //   Tokenization/TokenizerSetup.cs:36-43            (default delimiters)
 //   .NET BCL char.ToLowerInvariant / ToUpperInvariant / IsWhiteSpace / IsLetter
-//     (simple 1:1 case mapping; tables below cover ASCII, Latin-1, Latin Extended-A,
-//      basic Greek and Cyrillic — corpora used for parity are restricted to that range).
+//     (simple 1:1 case mappings of the whole BMP and the letter categories, from unicode_tables.hpp — generated from Unicode 13 data with .NET's
+//      two invariant exceptions; .NET 8 ships a newer Unicode: characters added after 13.0 are not covered)
 #pragma once
 #include <cstdint>
 #include <string>
 #include <vector>
 #include <array>
+#include "unicode_tables.hpp"
 
 namespace orc {
 
@@ -19,61 +20,29 @@ using u16 = char16_t;
 using ustr = std::u16string;
 using uview = std::u16string_view;
 
-// ---- .NET invariant simple case mapping (BMP subset) ------------------------------------
-inline u16 to_lower_inv(u16 c) {
-    if (c < 0x80) return (c >= u'A' && c <= u'Z') ? u16(c + 32) : c;
-    if (c >= 0x00C0 && c <= 0x00DE && c != 0x00D7) return u16(c + 32);
-    if (c >= 0x0100 && c <= 0x017F) {
-        if (c == 0x0130 || c == 0x0131) return c;            // Turkish dotted/dotless i: unchanged under invariant casing
-        if (c <= 0x0137) return (c & 1) ? c : u16(c + 1);    // 0100..0137 even->odd
-        if (c == 0x0138) return c;
-        if (c <= 0x0148) return (c & 1) ? u16(c + 1) : c;    // 0139..0148 odd->even
-        if (c == 0x0149) return c;
-        if (c <= 0x0177) return (c & 1) ? c : u16(c + 1);    // 014A..0177 even->odd
-        if (c == 0x0178) return 0x00FF;
-        if (c <= 0x017E) return (c & 1) ? u16(c + 1) : c;    // 0179..017E odd->even
-        return c;
+// ---- .NET invariant simple case mapping and letter set: generated from data (oracle/unicode_tables.hpp, tools/gen_unicode_tables.py) -------------
+struct CaseTables {
+    std::vector<u16> lower, upper; std::vector<uint32_t> letter;
+    CaseTables() : lower(65536), upper(65536) {
+        for (int i = 0; i < 65536; i++) { lower[i] = (u16)i; upper[i] = (u16)i; }
+        static const uint16_t lo[][2] = { INFX_UC_LOWER_PAIRS };
+        static const uint16_t up[][2] = { INFX_UC_UPPER_PAIRS };
+        static const uint32_t lt[] = { INFX_UC_LETTER_WORDS };
+        for (auto& pr : lo) lower[pr[0]] = pr[1];
+        for (auto& pr : up) upper[pr[0]] = pr[1];
+        letter.assign(lt, lt + 2048);
     }
-    if (c >= 0x0391 && c <= 0x03A9 && c != 0x03A2) return u16(c + 32);
-    if (c >= 0x0410 && c <= 0x042F) return u16(c + 32);
-    if (c >= 0x0400 && c <= 0x040F) return u16(c + 80);
-    return c;
-}
-inline u16 to_upper_inv(u16 c) {
-    if (c < 0x80) return (c >= u'a' && c <= u'z') ? u16(c - 32) : c;
-    if (c >= 0x00E0 && c <= 0x00FE && c != 0x00F7) return u16(c - 32);
-    if (c == 0x00FF) return 0x0178;
-    if (c >= 0x0100 && c <= 0x017F) {
-        if (c == 0x0130 || c == 0x0131) return c;
-        if (c <= 0x0137) return (c & 1) ? u16(c - 1) : c;
-        if (c == 0x0138) return c;
-        if (c <= 0x0148) return (c & 1) ? c : u16(c - 1);
-        if (c == 0x0149) return c;
-        if (c <= 0x0177) return (c & 1) ? u16(c - 1) : c;
-        if (c == 0x0178) return c;
-        if (c <= 0x017E) return (c & 1) ? c : u16(c - 1);
-        return c;
-    }
-    if (c >= 0x03B1 && c <= 0x03C9 && c != 0x03C2) return u16(c - 32);
-    if (c >= 0x0430 && c <= 0x044F) return u16(c - 32);
-    if (c >= 0x0450 && c <= 0x045F) return u16(c - 80);
-    return c;
-}
+};
+inline const CaseTables& case_tables() { static CaseTables t; return t; }
+inline u16 to_lower_inv(u16 c) { return case_tables().lower[c]; }      // char.ToLowerInvariant (U+0130 maps to itself)
+inline u16 to_upper_inv(u16 c) { return case_tables().upper[c]; }      // char.ToUpperInvariant (U+0131 maps to itself); OrdinalIgnoreCase compares these images
 inline ustr to_lower_inv(uview s) { ustr r(s); for (auto& c : r) c = to_lower_inv(c); return r; }
 
 inline bool is_whitespace(u16 c) {   // char.IsWhiteSpace
     return c == 0x20 || (c >= 0x09 && c <= 0x0D) || c == 0x85 || c == 0xA0 || c == 0x1680 ||
            (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
 }
-inline bool is_letter(u16 c) {       // char.IsLetter (subset: ASCII, Latin-1, Latin Ext-A/B, Greek, Cyrillic)
-    if (c < 0x80) return (c >= u'a' && c <= u'z') || (c >= u'A' && c <= u'Z');
-    if (c == 0xAA || c == 0xB5 || c == 0xBA) return true;
-    if (c >= 0xC0 && c <= 0x24F) return c != 0xD7 && c != 0xF7;
-    if (c >= 0x370 && c <= 0x3FF) return c != 0x375 && c != 0x37E && c != 0x384 && c != 0x385 && c != 0x387;
-    if (c >= 0x400 && c <= 0x481) return true;
-    if (c >= 0x48A && c <= 0x52F) return true;
-    return false;
-}
+inline bool is_letter(u16 c) { return (case_tables().letter[c >> 5] >> (c & 31)) & 1u; }      // char.IsLetter: Lu | Ll | Lt | Lm | Lo
 
 // OrdinalIgnoreCase primitives (compare after ToUpperInvariant per code unit)
 inline bool eq_ic(uview a, uview b) {
