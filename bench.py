@@ -226,7 +226,7 @@ def main():
     # set-up batches (another seed, never part of the warm-up or the timed stream): every session runs one before the warm-up so that its device
     # workspaces and pinned staging are allocated outside the measurement — with fewer warm-up steps than sessions some would otherwise grow theirs
     # (hipMalloc / hipHostMalloc) inside the timed region
-    sqa, sqo = syn.queries(args.batch, qseed=77000 + rank)
+    sqa, sqo = syn.queries(args.batch, qseed=77000 + (0 if sharded else rank))      # document shards answer the SAME batch on every rank (round 5: the per-rank seed made the ranks' collectives differ in size — found by the first two-rank run of this script)
     setup_batch = (np.ascontiguousarray(sqa[:int(sqo[-1])]) if sqo[-1] > 0 else np.zeros(1, np.uint16), sqo.astype(np.uint64))
 
     def sync():

@@ -43,6 +43,20 @@ def _stale(target, deps):
 def _build(lib, obj_dev, obj_host, extra, force, verbose):
     if not force and not _stale(lib, sources()):
         return lib                                   # up to date, whether or not the intermediate objects travelled with the tree
+    # one builder at a time: the ranks of a multi-process job (bench.py --gpus N, the two-rank tests) all call build() — two compilers writing the same
+    # object file left a half-written library behind and the second rank died loading it (round 5, on a tree whose sources were newer than its .so)
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale(lib, sources()):
+                return lib                           # another process built it while this one waited
+            return _build_locked(lib, obj_dev, obj_host, extra, force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(lib, obj_dev, obj_host, extra, force, verbose):
     # each object is rebuilt only when one of ITS sources changed: a host-side change leaves the device object (the kernels) byte for byte as it was
     cmds = []
     if force or _stale(obj_dev, device_sources()):
@@ -50,11 +64,13 @@ def _build(lib, obj_dev, obj_host, extra, force, verbose):
     if force or _stale(obj_host, host_sources()):
         cmds.append([HIPCC, *COMMON, "-march=x86-64-v3", "-x", "c++", "-c", os.path.join(CSRC, "host", "engine.cpp"), "-o", obj_host])
     if cmds or _stale(lib, [obj_dev, obj_host]):
-        cmds.append([HIPCC, "--offload-arch=gfx950", "-shared", "-o", lib, obj_dev, obj_host, "-lpthread"])
+        cmds.append([HIPCC, "--offload-arch=gfx950", "-shared", "-o", lib + ".tmp", obj_dev, obj_host, "-lpthread"])
     for c in cmds:
         if verbose:
             print(" ".join(c), file=sys.stderr)
         subprocess.check_call(c)
+    if os.path.exists(lib + ".tmp"):
+        os.replace(lib + ".tmp", lib)               # the library appears complete or not at all
     return lib
 
 
@@ -69,7 +85,16 @@ def build_experiments(force=False, verbose=False):
     return _build(LIB_EXP, os.path.join(CSRC, "infidex_hip_exp.o"), os.path.join(CSRC, "engine.o"), ["-DINFX_BUILD_EXPERIMENTS"], force, verbose)
 
 
+def build_variant(tag, defines, force=False, verbose=False):
+    """libinfidex_hip_<tag>.so = the product compiled with extra -D flags: A/B measurements of one kernel decision on the GPU box (INFX_LIB selects it)."""
+    return _build(os.path.join(HERE, f"libinfidex_hip_{tag}.so"), os.path.join(CSRC, f"infidex_hip_{tag}.o"), os.path.join(CSRC, "engine.o"), list(defines), force, verbose)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--experiments" in sys.argv:
         print(build_experiments(force="--force" in sys.argv, verbose=True))
+    for a in sys.argv[1:]:                                   # --variant=tag:-DX=1,-DY=2
+        if a.startswith("--variant="):
+            tag, _, defs = a[len("--variant="):].partition(":")
+            print(build_variant(tag, [d for d in defs.split(",") if d], force="--force" in sys.argv, verbose=True))

@@ -1246,6 +1246,9 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
     void* hs = nullptr;                                                // what a caller-supplied op with device buffers orders itself on: the session's hipStream_t
     if (dev && infx_stream_native(S->stream, &hs) != INFX_OK) return efail(INFX_EINVAL, "device exchange buffers need a session with a GPU stream");
     auto chk = [&](int32_t rc) { if (rc && g_eerr.empty()) g_eerr = infx_last_error(); return rc; };
+    // An error return leaves the rank's collective ring: a session that stays a member but issues no further collective would block every peer
+    // session of this rank in CollSeq::enter() for ever.  (The peer RANKS then see this session's collectives missing and time out: INFX_COMM_TIMEOUT_S.)
+    struct RetireOnError { infx_engine* e; infx_session* S; bool armed = true; ~RetireOnError() { if (armed) e->collSeq.retire(S); } } onError{e, S};
 #define XCHK(x) do { int32_t rc_ = chk(x); if (rc_) return rc_; } while (0)
     // one turn of the rank's collective ring per collective (CollSeq above); INFX_COLL_ORDER=0 switches the ordering off
     static const bool orderedEnv = [] { const char* v = getenv("INFX_COLL_ORDER"); return !(v && v[0] == '0'); }();
@@ -1337,6 +1340,7 @@ int32_t infx_session_sharded_finish(infx_session* S, const infx_comm* comm, int3
     XCHK(all_reduce(outs, (uint64_t)std::max<uint32_t>(nq, 1) * 2 * depth * 3));
     XCHK(infx_session_phase4(S, (const int32_t*)outs, out_keys, out_scores, out_ties, out_counts, out_flags));
 #undef XCHK
+    onError.armed = false;
     return INFX_OK;
 }
 

@@ -3,7 +3,7 @@
 // processes building it at once on the node's shared cores take W times the CPU work.  Instead the node's leader builds it once with every core and
 // writes it here (a file under /dev/shm); the other processes read it back — plain arrays, a couple of seconds — and upload their own shard.
 // The file is a transient hand-off between processes of ONE build on ONE node: raw little-endian arrays behind a header that pins the layout version,
-// the configuration the index was built with, the index fingerprint and a checksum of the payload; a truncated, foreign or altered file is refused.
+// the configuration the index was built with, the index fingerprint and a checksum of the payload; a truncated, foreign or corrupted file is refused (the checksum is an unkeyed multiply-xor hash: it detects damage, not tampering — the security boundary is the private 0700 directory with O_EXCL | O_NOFOLLOW and the ownership check).
 // The writer creates its file exclusively (O_EXCL | O_NOFOLLOW, mode 0600): a link somebody planted at the predictable path of a world-writable
 // directory is not written through.  It is not the reference's INFDX2 format (host/infdx2.h reads that).
 #pragma once

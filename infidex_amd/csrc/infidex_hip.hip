@@ -824,6 +824,7 @@ int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float
         HIPCHK(dalloc(ix, &dTO, (size_t)N + 1)); HIPCHK(dalloc(ix, &dTx, (size_t)tot));
         HIPCHK(hipMemcpy(dTO, text_offs, ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dTx, text, (size_t)tot * 2, hipMemcpyHostToDevice));
+        if (tot) { k_fold_ic<<<(unsigned)std::min<uint64_t>((tot + 255) / 256, 65536), 256>>>(dTx, (unsigned long long)tot); HIPCHK(hipGetLastError()); }      // OrdinalIgnoreCase fold (stage2.hip.inc)
     }
     if (ix->cfg.range_docs == 0) {   // default: wide ranges for large shards (fewer, longer per-range posting slices; measured best at 10M docs)
         int R = N >= (4u << 20) ? 8192 : N >= (1u << 20) ? 4096 : N >= (1u << 18) ? 2048 : 1024;
@@ -1337,6 +1338,7 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
     if (feat_out) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
     UP(s->dCovQ, q, (size_t)nq * sizeof(infx_cov_query));
+    k_fold_ic_queries<<<nq, WAVE, 0, s->st>>>((infx_cov_query*)s->dCovQ, nq);
     UP(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand));
     HIPCHK(hipEventRecord(s->evC0, s->st));
     S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq,
@@ -1462,8 +1464,7 @@ int32_t infx_ld1_expand(infx_stream* s, uint32_t nwords, const uint32_t* word_of
     // the rows are fetched in one strided pass up to the largest count of the batch
     uint32_t mx = 0; for (uint32_t i = 0; i < nwords; i++) if (!status_out[i]) mx = std::max(mx, std::min(counts_out[i], cap));
     if (mx) {
-        std::vector<int32_t> tmp((size_t)nwords * mx);
-        void* p = pin_take(s, tmp.size() * 4); if (!p) return fail(INFX_ENOMEM, "hipHostMalloc staging failed%s");
+        void* p = pin_take(s, (size_t)nwords * mx * 4); if (!p) return fail(INFX_ENOMEM, "hipHostMalloc staging failed%s");
         HIPCHK(hipMemcpy2DAsync(p, (size_t)mx * 4, s->dLMembers, (size_t)cap * 4, (size_t)mx * 4, nwords, hipMemcpyDeviceToHost, s->st)); s->unsynced = true;
         SYNC();
         for (uint32_t i = 0; i < nwords; i++) { const uint32_t c = status_out[i] ? 0u : std::min(counts_out[i], cap); std::memcpy(members_out + (size_t)i * cap, (const int32_t*)p + (size_t)i * mx, (size_t)c * 4); }
@@ -1587,6 +1588,7 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evP1, s->st));
+    k_fold_ic_queries<<<nq, WAVE, 0, s->st>>>((infx_cov_query*)s->dCovQ, nq);      // after k_wm: the dictionary lookups take the lower-cased words as they are
     HIPCHK(hipEventRecord(s->evC0, s->st));
     S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
                                                                                  (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 0, (const int32_t*)s->dFPairs);

@@ -177,6 +177,11 @@ int32_t orc_damerau(const uint16_t* a, int32_t la, const uint16_t* b, int32_t lb
 int32_t orc_lcs(const uint16_t* a, int32_t la, const uint16_t* b, int32_t lb, int32_t tol) {
     return lcs_metric(uview((const u16*)a, la), uview((const u16*)b, lb), tol);
 }
+// the generated case tables as the oracle uses them: 65536 entries each (lower, upper: code units; letter: 0 / 1)
+int32_t orc_case_tables(uint16_t* lower, uint16_t* upper, uint8_t* letter) {
+    for (int c = 0; c < 65536; c++) { lower[c] = to_lower_inv((u16)c); upper[c] = to_upper_inv((u16)c); letter[c] = is_letter((u16)c) ? 1 : 0; }
+    return 65536;
+}
 int32_t orc_normalize(const uint16_t* s, int32_t len, int lower, uint16_t* out, int32_t cap) {
     ustr r = default_normalizer().normalize(uview((const u16*)s, len));
     if (lower) r = to_lower_inv(r);

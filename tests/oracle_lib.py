@@ -229,6 +229,13 @@ def lcs(a, b, tol):
     return lib().orc_lcs(_p(x, C.c_uint16), len(x), _p(y, C.c_uint16), len(y), tol)
 
 
+def case_tables():
+    """char.ToLowerInvariant / ToUpperInvariant / IsLetter as the oracle applies them (oracle/unicode_tables.hpp), 65536 entries each."""
+    lo = np.zeros(65536, np.uint16); up = np.zeros(65536, np.uint16); le = np.zeros(65536, np.uint8)
+    lib().orc_case_tables(_p(lo, C.c_uint16), _p(up, C.c_uint16), _p(le, C.c_uint8))
+    return {"lower": lo, "upper": up, "letter": le}
+
+
 def normalize(s, lower=False):
     x = u16(s); out = np.zeros(len(x) + 8, np.uint16)
     n = lib().orc_normalize(_p(x, C.c_uint16), len(x), int(lower), _p(out, C.c_uint16), len(out))

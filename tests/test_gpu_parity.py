@@ -392,6 +392,57 @@ def test_random_unicode_corpora_full_parity():
         assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, (seed, st)
 
 
+def test_scripts_beyond_latin1_full_parity():
+    """Vietnamese, Latin Extended-B, accented / final-sigma Greek, Cyrillic beyond U+045F, Armenian, Georgian, full-width Latin, Cherokee, and the
+    characters OrdinalIgnoreCase equates with another lower-case letter: rows, scores and every Stage-2 feature equal the oracle's, whose case mappings
+    and letter set come from the same Unicode data as the product's (tools/gen_unicode_tables.py) and which compares per site as the reference does
+    (ToUpperInvariant images for OrdinalIgnoreCase, ToLowerInvariant where the reference lower-cases)."""
+    from tests import unicode_corpus
+    for si, script in enumerate(sorted(unicode_corpus.SCRIPTS)):
+        docs, queries = unicode_corpus.make_script(si, script, ndocs=300, nqueries=50)
+        e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+        o = O.OracleEngine.create_default(); o.index(docs)
+        st = compare_batch(e, o, queries, 10)
+        assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, (script, st)
+
+
+def test_ordinal_ignore_case_aliases():
+    """Where an alias character meets its base letter: OrdinalIgnoreCase compares ToUpperInvariant images, so a document word 'λογοσκοπος' starts with the query
+    word 'λογος' (final sigma and sigma share the capital), 'ſtraße' equals 'straße', 'µm' equals 'μm'.  The device text and query are folded for exactly that
+    (k_fold_ic); the returned DOCUMENTS must be the oracle's.  (Scores may differ by the reference's few ToLowerInvariant comparison sites, which see alias and
+    base as different characters: not compared here.)"""
+    docs = [(1, "λογοσκοπος αλφα"), (2, "λογος βητα"), (3, "ſtraße lang"), (4, "straße kurz"), (5, "10 µm filter"), (6, "10 μm sieve"), (7, "unrelated text here"),
+            (8, "ΛΟΓΟΣ ΚΕΦΑΛΑΙΑ"), (9, "ϑερμος ϕως"), (10, "θερμος φως")]
+    e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+    o = O.OracleEngine.create_default(); o.index(docs)
+    for q in ["λογος", "λογοσ", "straße", "ſtraße", "µm filter", "μm sieve", "θερμος", "ϑερμος φως", "ΛΟΓΟΣ"]:
+        got = [x.document_id for x in e.search(q, 10).records]
+        want = o.search(q, 10)["keys"]
+        assert sorted(got) == sorted(want), (q, got, want)
+
+
+ASTRAL_DOCS = [(1, "\U0001F50Dab zeta"), (2, "\U0001F50Eab yotta"), (3, "plain \U0001F50Dab"), (4, "x\U0001F50D \U0001F50Ex \U0001F50Dab"), (5, "\U0001F50D"),
+               (6, "\U00020000\U00020001 cjk\U00020001"), (7, "�ab already replaced"), (8, "x\U00020000 end"), (20, "emoji \U0001F600\U0001F601 party \U0001F600"),
+               (21, "\U0001D49C\U0001D4B7\U0001D4B8 math script"), (22, "mixed a\U0001F50Db c\U0001F50Ed"), (23, "\ud83d lone high"), (24, "lone low \udd0d tail")]
+ASTRAL_QUERIES = ["\U0001F50Dab", "\U0001F50Eab zeta", "a\U0001F50Db", "emoji \U0001F600", "\U0001D49C\U0001D4B7\U0001D4B8", "x\U0001F50D", "\U0001F50Dxb", "cjk\U00020001",
+                  "party \U0001F601\U0001F600", "\U0001F50Dab\U0001F50E", "\ud83d lone", "low \udd0d", "math script", "mixed"]
+
+
+def test_characters_outside_the_bmp_on_gpu():
+    """Surrogate pairs and lone surrogates through the whole device pipeline (k_wm, k_ld1, k_stage2 work on UTF-16 code units like the reference): rows and
+    scores equal the oracle's.  Staged in round 4 without GPU time; first run on an MI355X in round 5 (green).  The host side is covered on CPU by
+    test_host_parity.py::test_characters_outside_the_bmp_index_and_plan_like_the_oracle; the reference's PersistenceTests index U+1F50D."""
+    o = O.OracleEngine.create_default(); o.index(ASTRAL_DOCS)
+    e = SearchEngine.create_default(device=0); e.index_documents([Document(k, t) for k, t in ASTRAL_DOCS])
+    for q, r in zip(ASTRAL_QUERIES, e.search_batch(ASTRAL_QUERIES, 10)):
+        w = o.search(q, 10)
+        if w["unsupported"]:
+            assert r.records == [] or len(r.records) == 0, q
+            continue
+        assert [x.document_id for x in r.records] == w["keys"], (q, r.records, w)
+        assert np.allclose([x.score for x in r.records], w["scores"], rtol=0, atol=FINAL_ATOL), (q, r.records, w)
+
+
 def test_high_term_frequencies():
     """Documents that repeat a word up to 150 times: byte tf values from 2 to ~190 (Term.cs:87-109).  The replay kernels get tf >= 3 through the
     per-row exception records (k_accumulate) or the posting-list lookup."""

@@ -241,6 +241,48 @@ def test_random_unicode_corpora_index_and_plans_match_oracle():
             assert np.array_equal(prod.wordmatcher(q), orc.wordmatcher(_norm(q, lower=True))), (seed, q)
 
 
+def test_scripts_beyond_latin1_index_and_plan_like_the_oracle():
+    """Vietnamese, Latin Extended-B (title-case digraphs), accented / final-sigma Greek, Cyrillic beyond U+045F, Armenian, Georgian, full-width Latin,
+    Cherokee and the OrdinalIgnoreCase alias characters: the case tables of product and oracle are generated from Unicode data
+    (tools/gen_unicode_tables.py) — index arrays, term plans and WordMatcher sets of the two implementations must agree on every script."""
+    from infidex_amd import Document
+    from infidex_amd.engine import normalize as _norm
+    from tests import unicode_corpus
+    for si, script in enumerate(sorted(unicode_corpus.SCRIPTS)):
+        docs, queries = unicode_corpus.make_script(si, script, ndocs=200, nqueries=30)
+        prod = SearchEngine.create_default(device=-1, threads=3); prod.index_documents([Document(k, t) for k, t in docs])
+        orc = O.OracleEngine.create_default(); orc.index(docs)
+        a, b = prod.export_index(), orc.export_index()
+        assert prod.index_stats()["terms"] == orc.num_terms, script
+        for k in ("df", "post_off", "post_doc", "post_w", "doc_len"):
+            assert np.array_equal(a[k], b[k]), (script, k)
+        for q in queries:
+            p = prod.plan(q)
+            r = orc.search(q, 10)
+            if r["unsupported"]:
+                assert p["flags"] & 2, (script, q)
+                continue
+            t, df, idf, mx = orc.last_terms()
+            assert np.array_equal(p["term_ids"], t), (script, q)
+            assert np.array_equal(prod.wordmatcher(q), orc.wordmatcher(_norm(q, lower=True))), (script, q)
+
+
+def test_case_tables_known_answers():
+    """The generated tables against what .NET's char.ToLowerInvariant / ToUpperInvariant / IsLetter return for characters whose behaviour is documented:
+    simple (1:1) mappings only, U+0130 / U+0131 untouched by the invariant culture, title-case digraphs, final sigma, the sharp s, surrogates."""
+    from infidex_amd.engine import normalize as _norm
+    low = lambda s: _norm(s, lower=True)
+    assert low("ẢẤỆ") == "ảấệ" and low("ԱԲՖ") == "աբֆ" and low("ΆΈΏΫ") == "άέώϋ" and low("ＡＺ") == "ａｚ" and low("ѠҊԜ") == "ѡҋԝ"
+    assert low("ǅǄ") == "ǆǆ" and low("Σς") == "σς" and low("ẞ") == "ß" and low("Ⴀ") == "ⴀ" and low("Ꭰ") == "ꭰ"
+    assert low("\U0001F600") == "\U0001F600"                        # surrogate code units have no case
+    ot = O.case_tables()
+    assert ot["lower"][0x0130] == 0x0130 and ot["upper"][0x0131] == 0x0131 and ot["upper"][0x017F] == 0x53 and ot["upper"][0x00B5] == 0x039C
+    assert ot["upper"][0x03C2] == 0x03A3 and ot["lower"][0x03A3] == 0x03C3 and ot["upper"][0x00DF] == 0x00DF and ot["lower"][0x1E9E] == 0x00DF
+    assert ot["lower"][0x01C5] == 0x01C6 and ot["upper"][0x01C5] == 0x01C4 and ot["lower"][0x212A] == 0x6B and ot["upper"][0x212A] == 0x212A
+    for c, want in ((0x41, 1), (0x5F, 0), (0xAA, 1), (0xD7, 0), (0x2B0, 1), (0x345, 0), (0x37A, 1), (0x559, 1), (0x5D0, 1), (0x660, 0), (0x4E00, 1), (0xD800, 0), (0xFF21, 1), (0x2160, 0), (0x24B6, 0)):
+        assert ot["letter"][c] == want, hex(c)
+
+
 def test_random_synonym_maps_index_identically():
     """SynonymMap union-find (longer root wins, ordinal tie-break, chains, repeated and self pairs, mixed case): product == oracle."""
     import random

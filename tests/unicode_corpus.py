@@ -7,8 +7,35 @@ DELIMS = [" ", " ", " ", " ", "-", "/", ".", ",", ":", ";", "'", "`", "â€“", "â€
           " ", "  ", "\n", "Â§", "!"]
 
 
-def make(seed, ndocs=400, nqueries=60):
+# Scripts beyond Latin-1 / Latin Extended-A / basic Greek and Cyrillic (round 5: the case tables and the letter set come from Unicode data): Vietnamese
+# (Latin Extended Additional), Latin Extended-B digraphs incl. the title-case forms, accented and final-sigma Greek, Cyrillic beyond U+045F, Armenian,
+# Georgian (Asomtavruli -> Nuskhuri), full-width Latin, Cherokee, and the characters OrdinalIgnoreCase equates with another lower-case letter
+# (micro sign / mu, long s / s, final sigma / sigma, the Greek symbol forms).
+SCRIPTS = {
+    "vietnamese": list("áº£áº¢áº¥áº¤áº§áº¦áº©áº¨áº«áºªáº­áº¬áº¯áº®áº±áº°áº³áº²áºµáº´áº·áº¶áº¹áº¸áº»áººáº½áº¼áº¿áº¾á»á»€á»ƒá»‚á»…á»„á»‡á»†á»‰á»ˆá»‹á»Šá»á»Œá»á»á»‘á»á»“á»’á»•á»”á»—á»–á»™á»˜á»›á»šá»á»œá»Ÿá»á»¡á» á»£á»¢á»¥á»¤á»§á»¦á»©á»¨á»«á»ªá»­á»¬á»¯á»®á»±á»°á»³á»²á»µá»´á»·á»¶á»¹á»¸Ä‘Ä"),
+    "latin_ext_b": list("Ç„Ç…Ç†Ç‡ÇˆÇ‰ÇŠÇ‹ÇŒÆ€ÉƒÆÉ“Æ‚ÆƒÆ‡ÆˆÈ˜È™ÈšÈ›ÇÇÇÇÇ‘Ç’Ç“Ç”Ç•Ç–ÇÇŸÇºÇ»Ç¼Ç½Ç¾Ç¿È€ÈÈ¦È§È²È³"),
+    "greek": list("Î†Î¬ÎˆÎ­Î‰Î®ÎŠÎ¯ÎŒÏŒÎÏÎÏÎªÏŠÎ«Ï‹ÎÎ°Î±Î²Î³Î´ÎµÎ¶Î·Î¸Î¹ÎºÎ»Î¼Î½Î¾Î¿Ï€ÏÏƒÏ‚Ï„Ï…Ï†Ï‡ÏˆÏ‰Î‘Î’Î“Î”Î•Î–Î—Î˜Î™ÎšÎ›ÎœÎÎÎŸÎ Î¡Î£Î¤Î¥Î¦Î§Î¨Î©ÂµÏÏ‘Ï•Ï–Ï°Ï±Ïµ"),
+    "cyrillic_ext": list("Ñ Ñ¡Ñ¢Ñ£Ñ¤Ñ¥Ñ¦Ñ§ÑªÑ«ÒŠÒ‹ÒŒÒÒÒ‘Ò’Ò“Ò–Ò—ÒšÒ›Ò¢Ò£Ò®Ò¯Ò°Ò±Ò²Ò³ÒºÒ»Ó€ÓÓÓ‚ÓÓ‘Ó’Ó“Ó˜Ó™Ó¨Ó©Ô€ÔÔÔ‘ÔšÔ›ÔœÔ"),
+    "armenian": list("Ô±Ô²Ô³Ô´ÔµÔ¶Ô·Ô¸Ô¹ÔºÔ»Ô¼Ô½Ô¾Ô¿Õ€ÕÕ‚ÕƒÕ„Õ…Õ†Õ‡ÕˆÕ‰ÕŠÕ‹ÕŒÕÕÕÕÕ‘Õ’Õ“Õ”Õ•Õ–Õ¡Õ¢Õ£Õ¤Õ¥Õ¦Õ§Õ¨Õ©ÕªÕ«Õ¬Õ­Õ®Õ¯Õ°Õ±Õ²Õ³Õ´ÕµÕ¶Õ·Õ¸Õ¹ÕºÕ»Õ¼Õ½Õ¾Õ¿Ö€ÖÖ‚ÖƒÖ„Ö…Ö†Ö‡"),
+    "georgian": list("á‚ á‚¡á‚¢á‚£á‚¤á‚¥á‚¦á‚§á‚¨á‚©á‚ªá‚«á‚¬á‚­á‚®á‚¯á‚°á‚±á‚²á‚³á‚´á‚µâ´€â´â´‚â´ƒâ´„â´…â´†â´‡â´ˆâ´‰â´Šâ´‹â´Œâ´â´â´â´â´‘â´’â´“â´”â´•áƒáƒ‘áƒ’áƒ“áƒ”áƒ•áƒ–áƒ—áƒ˜"),
+    "fullwidth": list("ï¼¡ï¼¢ï¼£ï¼¤ï¼¥ï¼¦ï¼§ï¼¨ï¼©ï¼ªï¼«ï¼¬ï¼­ï¼®ï¼¯ï¼°ï¼±ï¼²ï¼³ï¼´ï¼µï¼¶ï¼·ï¼¸ï¼¹ï¼ºï½ï½‚ï½ƒï½„ï½…ï½†ï½‡ï½ˆï½‰ï½Šï½‹ï½Œï½ï½ï½ï½ï½‘ï½’ï½“ï½”ï½•ï½–ï½—ï½˜ï½™ï½šï¼ï¼‘ï¼’"),
+    "cherokee": list("á á¡á¢á£á¤á¥á¦á§á¨á©ê­°ê­±ê­²ê­³ê­´ê­µê­¶ê­·ê­¸ê­¹á°á±á²á³á´áµá¸á¹áºá»á¼á½"),
+    # the lower-case characters OrdinalIgnoreCase equates with ANOTHER lower-case letter (long s, micro sign, final sigma, the Greek symbol forms, ypogegrammeni,
+    # long s with dot, Cyrillic Extended-C) WITHOUT their base letters: alone they behave like any other letter at every comparison site; where an alias meets
+    # its base letter the reference's OrdinalIgnoreCase sites and its ToLowerInvariant sites disagree with each other (tests/test_gpu_parity.py::test_ordinal_ignore_case_aliases)
+    "aliases": list("Å¿ÂµÏ‚ÏÏ‘Ï•Ï–Ï°Ï±Ïµáº›á²€á²á²‚á²ƒá²„á²†á²‡xyzXYZ"),
+}
+
+
+def make_script(seed, script, ndocs=300, nqueries=50):
+    """A corpus whose words are drawn from ONE script's alphabet mixed with ASCII (so that case pairs, title-case forms and alias characters meet)."""
+    # (no upper-cased documents for the alias characters: their capitals are the BASE letters' capitals, which would bring the base letters in)
+    return make(seed, ndocs, nqueries, alphabet=SCRIPTS[script] + list("abcdeABCDE019"), upper_docs=script != "aliases")
+
+
+def make(seed, ndocs=400, nqueries=60, alphabet=None, upper_docs=True):
     rng = random.Random(100 + seed)
+    ALPHABET = alphabet or globals()["ALPHABET"]
     vocab = ["".join(rng.choice(ALPHABET) for _ in range(rng.choice([1, 2, 3, 4, 5, 6, 8, 11]))) for _ in range(120)]
     docs = []
     for i in range(ndocs):
@@ -16,7 +43,7 @@ def make(seed, ndocs=400, nqueries=60):
         t = "".join(rng.choice(vocab) + rng.choice(DELIMS) for _ in range(n))
         if rng.random() < 0.1 and docs:
             t = docs[rng.randrange(len(docs))][1]          # duplicate text
-        if rng.random() < 0.05:
+        if rng.random() < 0.05 and upper_docs:
             t = " " + t.upper() + "\t"
         docs.append((i, t))
     queries = []
