@@ -14,7 +14,8 @@ DELIMS = [" ", " ", " ", " ", "-", "/", ".", ",", ":", ";", "'", "`", "โ", "โ
 SCRIPTS = {
     "vietnamese": list("แบฃแบขแบฅแบคแบงแบฆแบฉแบจแบซแบชแบญแบฌแบฏแบฎแบฑแบฐแบณแบฒแบตแบดแบทแบถแบนแบธแบปแบบแบฝแบผแบฟแบพแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปแปกแปแปฃแปขแปฅแปคแปงแปฆแปฉแปจแปซแปชแปญแปฌแปฏแปฎแปฑแปฐแปณแปฒแปตแปดแปทแปถแปนแปธฤฤ"),
     "latin_ext_b": list("วววววววววฦษฦษฦฦฦฦศศศศวววววววววววววบวปวผวฝวพวฟศศศฆศงศฒศณ"),
-    "greek": list("ฮฮฌฮฮญฮฮฎฮฮฏฮฯฮฯฮฯฮชฯฮซฯฮฮฐฮฑฮฒฮณฮดฮตฮถฮทฮธฮนฮบฮปฮผฮฝฮพฮฟฯฯฯฯฯฯฯฯฯฯฮฮฮฮฮฮฮฮฮฮฮฮฮฮฮฮฮกฮฃฮคฮฅฮฆฮงฮจฮฉยตฯฯฯฯฯฐฯฑฯต"),
+    # (without final sigma and the symbol forms: they share their capitals with sigma, beta, theta ... โ see "aliases" below)
+    "greek": list("ฮฮฌฮฮญฮฮฎฮฮฏฮฯฮฯฮฯฮชฯฮซฯฮฮฐฮฑฮฒฮณฮดฮตฮถฮทฮธฮนฮบฮปฮผฮฝฮพฮฟฯฯฯฯฯฯฯฯฯฮฮฮฮฮฮฮฮฮฮฮฮฮฮฮฮฮกฮฃฮคฮฅฮฆฮงฮจฮฉ"),
     "cyrillic_ext": list("ัักัขัฃัคัฅัฆังัชัซาาาาาาาาาาาาาขาฃาฎาฏาฐาฑาฒาณาบาปำำำำำำำำำำำจำฉิิิิิิิิ"),
     "armenian": list("ิฑิฒิณิดิติถิทิธินิบิปิผิฝิพิฟีีีีีีีีีีีีีีีีีีีีีีีีกีขีฃีคีฅีฆีงีจีฉีชีซีฌีญีฎีฏีฐีฑีฒีณีดีตีถีทีธีนีบีปีผีฝีพีฟึึึึึึึึ"),
     "georgian": list("แแกแขแฃแคแฅแฆแงแจแฉแชแซแฌแญแฎแฏแฐแฑแฒแณแดแตโดโดโดโดโดโดโดโดโดโดโดโดโดโดโดโดโดโดโดโดโดโดแแแแแแแแแ"),
