@@ -201,6 +201,14 @@ int32_t infx_segment_export(infx_segment* seg, uint32_t* term_offs /* T+1 */, ui
  * weight) postings inside that range, and every index term with postings in the range must be in the segment.  checked3 (optional): documents, terms, postings
  * compared.  INFX_EINVAL for a foreign or corrupted file, INFX_EUNSUPPORTED when segment and index disagree. */
 int32_t infx_engine_verify_segment(infx_engine* e, const char* path, int32_t doc_base, int64_t* checked3);
+/* An engine populated from FLUSHED SEGMENTS + a live tail instead of infx_engine_index_documents (VectorModel.Flush, Indexing/VectorModel.cs:804-815;
+ * Indexing/Segments/SegmentReader.cs): segment i holds the postings of documents [doc_bases[i], doc_bases[i] + its document count); the segments cover the
+ * documents from 0 without gaps, in order; documents behind the last segment are the live tail.  The flushed ranges' posting lists come from the files, only the
+ * tail's are accumulated from the texts.  All n documents are supplied (term ids, document lengths, WordMatcher dictionaries and Stage-2 texts need them).
+ * The corpus is then searched as ONE index (= an unflushed index of the same documents), not segment by segment as VectorModel.cs:572-584 does.
+ * INFX_EUNSUPPORTED: a segment written from other documents; the engine stays unindexed. */
+int32_t infx_engine_index_from_segments(infx_engine* e, int64_t n, const int64_t* keys, const uint16_t* arena, const uint64_t* offs, int32_t field_count, const int32_t* field_weights,
+                                        int32_t n_segments, const char* const* paths, const int32_t* doc_bases);
 int32_t infx_engine_restore_documents(infx_engine* e);      /* clears every Deleted flag */
 /* One host-index build per node instead of one per rank (document shards: every process needs the whole host index — global df / avgdl / N, the term and
  * word dictionaries, the WordMatcher lists).  The node's leader indexes the documents (infx_engine_set_build_threads lets that build use every

@@ -230,6 +230,34 @@ int32_t infx_engine_index_documents(infx_engine* e, int64_t n, const int64_t* ke
     e->keysAreIds = (keys == nullptr);
     return finish_index(e);
 }
+// An engine populated from FLUSHED SEGMENTS + a live tail (VectorModel.Flush, VectorModel.cs:804-815): segment i holds the postings of documents
+// [doc_bases[i], doc_bases[i] + its document count), the segments cover the documents from 0 without gaps, the documents behind them are the live tail.  The
+// posting lists of the flushed ranges are taken from the files (read and validated by host/infs.h) — only the tail's postings are accumulated from the texts;
+// term ids, document lengths, the WordMatcher dictionaries, prefix sets and the Stage-2 texts need the documents, so all n documents are supplied.  The engine
+// then searches the whole corpus as ONE index.  (The reference answers a mixed index segment by segment, every segment with its own tier decisions and its own
+// top-k heap, merged afterwards — VectorModel.cs:572-584: an index-lifecycle artefact this does not imitate; an unflushed index of the same documents is what
+// it equals, and what tests/test_infs.py checks against the oracle.)
+int32_t infx_engine_index_from_segments(infx_engine* e, int64_t n, const int64_t* keys, const uint16_t* arena, const uint64_t* offs, int32_t field_count, const int32_t* field_weights,
+                                        int32_t n_segments, const char* const* paths, const int32_t* doc_bases) {
+    if (!e || n < 0 || (n && (!arena || !offs)) || field_count < 1 || !field_weights || n_segments < 0 || (n_segments && (!paths || !doc_bases))) return efail(INFX_EINVAL, "bad arguments");
+    if (e->indexed) return efail(INFX_EINVAL, "this engine instance is already indexed (re-indexing: create a new engine)");
+    if (n > 0x7FFFFFF0ll) return efail(INFX_EINVAL, "too many documents");
+    for (int64_t i = 0, m = n * field_count; i < m; i++) if (offs[i + 1] < offs[i]) return efail(INFX_EINVAL, "field offsets must be ascending (offs[n * field_count] = the arena's length)");
+    std::vector<infs::Segment> files((size_t)n_segments); std::vector<SegmentPostings> segs((size_t)n_segments);
+    for (int32_t i = 0; i < n_segments; i++) {
+        if (!paths[i]) return efail(INFX_EINVAL, "null segment path");
+        if (!infs::read_file(paths[i], files[i])) return efail(INFX_EINVAL, "INFS segment: " + files[i].error);
+        segs[i].docBase = doc_bases[i]; segs[i].docCount = files[i].docCount; segs[i].terms = &files[i].terms; segs[i].off = &files[i].off; segs[i].doc = &files[i].doc; segs[i].w = &files[i].w;
+    }
+    DocSource src{n, field_count, field_weights, keys, (const u16*)arena, offs};
+    const int planThreads = e->ix.cfg.threads;
+    if (e->buildThreads > 0) e->ix.cfg.threads = e->buildThreads;
+    const char* err = build_index(src, e->ix, &segs);
+    e->ix.cfg.threads = planThreads;
+    if (err) { const HostConfig cfg = e->ix.cfg; e->ix = HostIndex(); e->ix.cfg = cfg; return efail(INFX_EUNSUPPORTED, std::string("index from segments: ") + err); }      // the engine stays unindexed and reusable
+    e->keysAreIds = (keys == nullptr);
+    return finish_index(e);
+}
 
 
 // The dictionaries of the planning lookups go to the device next to the lists they resolve to (include/infidex_hip.h "Dictionary lookups"): WordMatcher

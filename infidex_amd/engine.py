@@ -174,6 +174,17 @@ class SearchEngine:
                                                        _p(offs, C.c_uint64), len(fw), _p(fw, C.c_int32)))
         self._keep = None
 
+    def index_flat_from_segments(self, keys, arena, offs, field_weights, segment_paths, doc_bases):
+        """An engine populated from flushed INFS segments + a live tail (VectorModel.Flush): the posting lists of the flushed document ranges come from the
+        files, the documents supply everything else (infx_engine_index_from_segments); the corpus is then searched as one index."""
+        fw = np.asarray(field_weights, np.int32)
+        n = (len(offs) - 1) // len(fw)
+        keys = None if keys is None else np.ascontiguousarray(keys, np.int64)
+        paths = (C.c_char_p * len(segment_paths))(*[str(p).encode() for p in segment_paths])
+        bases = np.ascontiguousarray(doc_bases, np.int32)
+        self._check(self.L.infx_engine_index_from_segments(self.h, C.c_int64(n), _p(keys, C.c_int64), _p(arena, C.c_uint16), _p(offs, C.c_uint64), len(fw), _p(fw, C.c_int32),
+                                                            len(segment_paths), paths, _p(bases, C.c_int32)))
+
     def load_index(self, path: str):
         """SearchEngine.Load (SearchEngine.cs:399-441) of an INFDX2 file: indexes the stored documents and verifies every stored term / posting against
         the index just built (infx_engine_load_index).  Returns (documents, stored terms compared, stored postings compared)."""

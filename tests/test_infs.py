@@ -186,6 +186,65 @@ def test_flipped_bits_never_get_past_the_bounds_checks(tmp_path):
     assert refused > 300
 
 
+def _flush_like(o, tmp_path, cuts):
+    """Segment files as a sequence of Flush calls would leave them: documents [cuts[i], cuts[i + 1]) each, ids relative to the segment's first document."""
+    paths, bases = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        p = str(tmp_path / f"flush{lo}.seg"); W.write(p, _oracle_terms(o, lo, hi), hi - lo)
+        paths.append(p); bases.append(lo)
+    return paths, bases
+
+
+def test_an_engine_populated_from_segments_holds_the_index_of_the_documents(tmp_path):
+    """Two flushed segments + a live tail -> infx_engine_index_from_segments: the flushed ranges' postings come from the files (only the tail's are accumulated
+    from the texts) and the host index is, array for array, the one infx_engine_index_documents builds from the same documents.  A segment written from other
+    documents is refused and leaves the engine reusable."""
+    s = Synth(2, docs=6000); arena, offs = s.docs()
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    paths, bases = _flush_like(o, tmp_path, [0, 2500, 4700])                      # tail: documents [4700, 6000)
+    e = SearchEngine.create_default(device=-1); e.index_flat_from_segments(None, arena, offs, s.field_weights, paths, bases)
+    ref = SearchEngine.create_default(device=-1); ref.index_flat(None, arena, offs, s.field_weights)
+    a, b = e.export_index(), ref.export_index()
+    assert e.index_stats() == ref.index_stats()
+    for k in ("df", "post_off", "post_doc", "post_w", "doc_len"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["avgdl"] == b["avgdl"]
+    qa, qo = s.queries(40, qseed=3)
+    for q in Synth.texts(qa, qo):
+        pa, pb = e.plan(q), ref.plan(q)
+        assert np.array_equal(pa["term_ids"], pb["term_ids"]) and np.array_equal(pa["idf"], pb["idf"]), q
+    # no segments at all: everything is the live tail
+    e0 = SearchEngine.create_default(device=-1); e0.index_flat_from_segments(None, arena, offs, s.field_weights, [], [])
+    assert np.array_equal(e0.export_index()["post_doc"], b["post_doc"])
+    # segments of OTHER documents / with a gap / out of order: refused, and the engine can still be indexed
+    bad = SearchEngine.create_default(device=-1)
+    with pytest.raises(Exception):
+        bad.index_flat_from_segments(None, arena, offs, s.field_weights, paths[1:], bases[1:])       # does not start at document 0
+    with pytest.raises(Exception):
+        bad.index_flat_from_segments(None, arena, offs, s.field_weights, paths, [0, 2400])           # gap / overlap
+    other = str(tmp_path / "other.seg"); W.write(other, [("zzzzzzzz", [0, 1], [1, 1])], 2500)
+    with pytest.raises(Exception):
+        bad.index_flat_from_segments(None, arena, offs, s.field_weights, [other], [0])               # a term the documents do not produce
+    bad.index_flat(None, arena, offs, s.field_weights)
+    assert np.array_equal(bad.export_index()["post_doc"], b["post_doc"])
+
+
+@pytest.mark.gpu
+def test_an_engine_populated_only_from_segments_searches_like_the_oracle(tmp_path):
+    """30 000 documents: two flushed segments + a live tail, no infx_engine_index_documents — searches equal the oracle's on the same documents."""
+    from tests.parity_classify import assert_final_rows_match_oracle
+    from infidex_amd.engine import pack_texts
+    s = Synth(2, docs=30000); arena, offs = s.docs()
+    o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
+    paths, bases = _flush_like(o, tmp_path, [0, 12000, 26000])
+    e = SearchEngine.create_default(device=0); e.index_flat_from_segments(None, arena, offs, s.field_weights, paths, bases)
+    qa, qo = s.queries(200, qseed=11)
+    texts = Synth.texts(qa, qo)
+    a2, o2 = pack_texts(texts)
+    k, sc, t, c, f = e.search_packed(a2, o2, 10)
+    assert_final_rows_match_oracle(k, sc, c, o, texts, 10, what="engine populated from two segments + a live tail")
+
+
 @pytest.mark.gpu
 def test_a_verified_segment_is_the_index_the_gpu_searches(tmp_path):
     """Flush-style segments of a corpus (two flushes) verified against the GPU engine's index of the same documents; the segment's CSR, mapped from term ordinals to
