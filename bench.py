@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 HBM_COPY_GBS = 6290.0     # the measured copy rate of the same guide: SURVEY 8(d) asks for the fraction of it next to the fraction of the spec
 
 
-PMC_FILE = "r04_pmc.json"
+PMC_FILE = "r05_pmc.json"
 
 
 def kernel_sha16():
@@ -56,9 +56,9 @@ def roofline_by_kernel(roof):
     spec = [
         # kernel, duration key, algorithmic bytes, bound, what the bytes are
         ("k_select", "k_select_ms", rows * 9.0, "latency", "arena rows x (class 1 B + score 4 B + doc id 4 B), each read once (the radix select reads class + score once per pass: 2-3 passes)"),
-        ("k_ex_scan", "k_ex_scan_ms", m("replay_rows") * 12.0, "serial-latency", "rows of the flagged queries x (class 1 B + score 4 B + directory / candidate-list 7 B): one workgroup per query walks them in doc order"),
-        ("k_ex_chunk", "k_ex_chunk_ms", m("replay_rows") * (4.0 + 8.0 + 4.0 + 4.0), "issue", "candidate rows of the flagged queries x (list entry 4 B + hit mask 8 B + tf exceptions 4 B + doc length 4 B)"),
-        ("k_ex_heap", "k_ex_heap_ms", m("replay_rows") * 8.0, "serial-latency", "emitted candidates x (doc 4 B + score 4 B); time = ~3-4 k dependent 4-ary heap operations per query on one wave"),
+        ("k_ex_scan", "k_ex_scan_ms", m("replay_rows") * 12.0, "serial-latency", "k_ex_walk x2 + k_ex_prefix + k_ex_theta: rows of the flagged queries x (class 1 B + score 4 B + directory / candidate-list 7 B); the time is k_ex_theta's ~1 400 serial sorted insertions per query on one wave"),
+        ("k_ex_chunk", "k_ex_chunk_ms", m("replay_rows") * (4.0 + 8.0 + 4.0 + 4.0), "latency", "k_ex_chunk<1|4|16>: candidate rows of the flagged queries x (list entry 4 B + hit mask 8 B + tf exceptions 4 B + doc length 4 B); three dependent loads + the term loop per chunk task"),
+        ("k_ex_heap", "k_ex_heap_ms", m("replay_rows") * 8.0, "serial-latency", "emitted candidates x (doc 4 B + score 4 B); time = ~2 k dependent 4-ary heap operations per query on one wave (register-resident heap: ~1 200 cycles each)"),
         ("k_prep2", "k_prep2_ms", nq * 500 * 8.0 + s2rows * 16.0, "latency", "Stage-1 rows in (8 B) + candidate rows out (16 B) + WordMatcher list probes (binary searches)"),
         ("k_stage2", "k_stage2_ms", s2bytes + s2rows * (16.0 + 12.0), "issue", "UTF-16 text of every scored row + candidate row in (16 B) + result out (12 B); integer string code, one lane per row"),
     ]
@@ -386,7 +386,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS, "traffic": None,
                      "limiter": "instruction issue and latency, not bandwidth: the kernel is priced against the HBM roofline (byte streaming, no MFMA work) but its "
                                 "time is set by the VALU / SALU / LDS instructions of the (posting list, doc range) visits - vector ALUs 72 % busy, 46 % of a wave's time in "
-                                "s_waitcnt (profiles/r03_final_10m.md); a kernel that only loads random 512-byte slices reaches 5.2-5.7 TB/s on this GPU (tools/bench_slices.hip)",
+                                "s_waitcnt (profiles/r05_final_10m.md, r05_pmc.json); a kernel that only loads random 512-byte slices reaches 5.2-5.7 TB/s on this GPU (tools/bench_slices.hip)",
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": acc_ms,
                      "streamed_bytes_per_launch": streamed, "stage1_candidates_per_launch": float(np.mean([t["stage1_candidates"] for t in roof])),
                      "stage2_rows_per_launch": float(np.mean([t["stage2_candidates"] for t in roof])), "exact_replays_per_launch": float(np.mean([t["exact_replays"] for t in roof])), "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,

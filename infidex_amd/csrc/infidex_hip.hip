@@ -278,7 +278,7 @@ struct infx_stream {
     void* dHitCount = nullptr; size_t capHitCount = 0;
     void* dBlockOut = nullptr; size_t capBlockOut = 0;
     void* dBlockOutHi = nullptr; size_t capBlockOutHi = 0;
-    void* dQBytes = nullptr; size_t capQBytes = 0;
+    void* dQBytes = nullptr; size_t capQBytes = 0; uint32_t lastNqAlloc = 0;
     void* dUOffs = nullptr; size_t capUOffs = 0; void* dUMem = nullptr; size_t capUMem = 0; void* dUCnt = nullptr; size_t capUCnt = 0;
     void* dURange = nullptr; size_t capURange = 0; void* dUBase = nullptr; size_t capUBase = 0; void* dUDocs = nullptr; size_t capUDocs = 0;
     struct PinChunk { char* base; size_t cap, off; }; std::vector<PinChunk> pins;      // pinned staging arena
@@ -295,6 +295,7 @@ struct infx_stream {
     unsigned long long* arMask = nullptr; size_t arMaskCap = 0; int maskWords = 0;     // per-row hit masks of the last accumulate launch
     uint32_t* arExc = nullptr; uint32_t* exCand = nullptr; infx_hit* exOut = nullptr; size_t exCap = 0;       // tf exception records, candidate lists, replay rows (arena-sized)
     void* exChunks = nullptr; size_t capExChunks = 0; void* exQueries = nullptr; size_t capExQueries = 0; void* exTasks = nullptr; size_t capExTasks = 0; uint32_t* exCounters = nullptr;
+    void* dSelOrder = nullptr; size_t capSelOrder = 0;        // k_select_order: the batch's queries by row count, descending
     void* exContEnd = nullptr; size_t capExContEnd = 0;      // k_ex_cand: candidates up to the end of every (query, container)
     uint32_t exChunkCap = 0; size_t arBound = 0;
     void* dDir = nullptr; size_t capDir = 0;
@@ -483,7 +484,7 @@ static void launch_union_any(infx_stream* s, uint32_t nv, const uint32_t* dBeg, 
 static bool exact_enabled(const infx_index* ix) { static const bool v = [] { const char* e = getenv("INFX_EXACT"); return !(e && e[0] == '0'); }(); return v && !(ix->cfg.flags & INFX_CFG_NO_EXACT_REPLAY); }
 static Arena make_arena(infx_stream* s) {
     return Arena{s->arDoc, s->arScore, s->arCls, s->arMask, s->arExc, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
-                 (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes, (uint2*)s->dDir, s->maskWords};
+                 (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes, (uint32_t*)((unsigned long long*)s->dQBytes + s->lastNqAlloc), (uint2*)s->dDir, s->maskWords};
 }
 static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX_ACC_STRIPE"); int x = e ? atoi(e) : 0; return (x >= 1 && x <= 64) ? x : 4; }(); return v; }
 // LDS8 (stage1.hip.inc) addresses the tf array by raw LDS offset: true only while k_accumulate owns no static __shared__ data, i.e. its dynamic
@@ -605,6 +606,14 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
         fprintf(stderr, "[infx] k_accumulate stats: %llu blocks with candidates of %llu, %.2f rounds/block, %.1f candidates/block\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0); }
 }
 
+// Longest-queries-first order for k_select's workgroups (k_select_order, stage1.hip.inc); nullptr: query order (batches beyond SEL_ORDER_MAX, INFX_SELECT_LPT=0)
+static const uint32_t* select_order(infx_stream* s, uint32_t nq) {
+    static const bool off = [] { const char* e = getenv("INFX_SELECT_LPT"); return e && e[0] == '0'; }();
+    if (off || nq < 64 || nq > SEL_ORDER_MAX) return nullptr;
+    if (grow(s, &s->dSelOrder, &s->capSelOrder, (size_t)nq * 4)) return nullptr;
+    k_select_order<<<1, 1024, 0, s->st>>>((const uint32_t*)s->dBlockOutHi, nq, (uint32_t*)s->dSelOrder);
+    return (const uint32_t*)s->dSelOrder;
+}
 // k_exact1 behind k_select: unsharded indexes only (the reference's chunking follows GLOBAL 65 536-id containers and its heap is sequential
 // over the whole corpus; document shards keep k_select's deterministic (score, doc id) cut)
 static bool exact_slow_only() { static const bool v = [] { const char* e = getenv("INFX_EXACT_SLOW"); return e && e[0] == '1'; }(); return v; }
@@ -1067,7 +1076,7 @@ void infx_stream_destroy(infx_stream* s) {
     hipSetDevice(s->ix->cfg.device);
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
-                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters, s->exContEnd, s->dExProf,
+                  s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters, s->exContEnd, s->dExProf, s->dSelOrder,
                   s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount, s->dDense};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
@@ -1218,7 +1227,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     GROW(s->dUDocs, s->capUDocs, 16); GROW(s->dURange, s->capURange, 4);
     GROW(s->dBlockOut, s->capBlockOut, ((size_t)nq + 1) * 8);      // qBase
     GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * 4);        // qCursor
-    GROW(s->dQBytes, s->capQBytes, (size_t)nq * 8);
+    GROW(s->dQBytes, s->capQBytes, (size_t)nq * 12); s->lastNqAlloc = nq;      // per query: algorithmic bytes (u64) | best emitted score bits (u32, behind the nq u64s)
     GROW(s->dCounts, s->capCounts, (size_t)nq * INFX_NCLASS * 4);
     {   // k_accumulate_sr's per-(query, container) hand-over flags (INFX_ACC_SR=0: everything through k_accumulate)
 #ifdef INFX_BUILD_EXPERIMENTS
@@ -1238,7 +1247,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     HIPCHK(hipMemsetAsync(s->dExactFlag, 0, (size_t)nq * 4, s->st));
     UP(s->dExtra, extra_docs, (size_t)extra_n * 4);
     UP(s->dBlockOut, qbase.data(), ((size_t)nq + 1) * 8);
-    HIPCHK(hipMemsetAsync(s->dQBytes, 0, (size_t)nq * 8, s->st));
+    HIPCHK(hipMemsetAsync(s->dQBytes, 0, (size_t)nq * 12, s->st));
     HIPCHK(hipMemsetAsync(s->dOverflow, 0, 4, s->st));
     HIPCHK(hipMemsetAsync(s->dCounts, 0, (size_t)nq * INFX_NCLASS * 4, s->st));
     HIPCHK(hipMemsetAsync(s->dBlockOutHi, 0, (size_t)nq * 4, s->st));
@@ -1300,7 +1309,7 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     HIPCHK(hipEventRecord(s->evS0, s->st));
     const bool exact = exact_possible(s);
     if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
-    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr, nullptr);
+    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr, nullptr, select_order(s, nq));
     if (exact) { int32_t rc_ = enqueue_exact(s, nq, maxDepth); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evS1, s->st));
@@ -1524,7 +1533,7 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, 
         if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
         if (shardNext) GROW(s->dNext, s->capNext, (size_t)nd * 4);       // document shards: no local flags — the cut is global (k_gflag)
         k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr,
-                                                shardNext ? (float*)s->dNext : nullptr);
+                                                shardNext ? (float*)s->dNext : nullptr, select_order(s, nd));
         if (markTurn) { HIPCHK(hipEventRecord(s->evTurn, s->st)); markTurn = false; }      // the wide phase of this batch ends here
         if (exact) { int32_t rc_ = enqueue_exact(s, nd, depth); if (rc_) return rc_; }
     }
