@@ -647,9 +647,9 @@ static int32_t launch_scan_and_chunks(infx_stream* s, uint32_t nq, Arena ar, ExB
     infx_index* ix = s->ix;
     const int rpc = 65536 / ix->d.R, nCont = (ix->d.nRanges + rpc - 1) / rpc;
     if (nCont > 65535) return fail(INFX_ECAPACITY, "exact replay: more than 65535 containers of 65536 documents in one shard%s");
-    k_ex_walk<false><<<dim3(nq, nCont), EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag, xb, nCont);
+    k_ex_walk<false><<<dim3(nq, nCont), WAVE, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag, xb, nCont);
     k_ex_prefix<<<nq, EXS_THREADS, 0, s->st>>>((const uint32_t*)s->dExactFlag, xb, nCont);
-    k_ex_walk<true><<<dim3(nq, nCont), EXS_THREADS, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag, xb, nCont);
+    k_ex_walk<true><<<dim3(nq, nCont), WAVE, 0, s->st>>>(ix->d, ar, (const SelRule*)s->dRules, (const uint32_t*)s->dExactFlag, xb, nCont);
     k_ex_theta<<<nq, WAVE, 0, s->st>>>(ar, (const SelRule*)s->dRules, (uint32_t*)s->dExactFlag, xb, prior, nCont);
     HIPCHK(hipEventRecord(s->evXa, s->st));
     hipStream_t bigSt = s->st;
