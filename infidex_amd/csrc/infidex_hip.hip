@@ -1347,7 +1347,7 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
     if (feat_out) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
     UP(s->dCovQ, q, (size_t)nq * sizeof(infx_cov_query));
-    k_fold_ic_queries<<<nq, WAVE, 0, s->st>>>((infx_cov_query*)s->dCovQ, nq);
+    if (nq) k_fold_ic_queries<<<nq, WAVE, 0, s->st>>>((infx_cov_query*)s->dCovQ, nq);
     UP(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand));
     HIPCHK(hipEventRecord(s->evC0, s->st));
     S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq,
@@ -1597,7 +1597,7 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evP1, s->st));
-    k_fold_ic_queries<<<nq, WAVE, 0, s->st>>>((infx_cov_query*)s->dCovQ, nq);      // after k_wm: the dictionary lookups take the lower-cased words as they are
+    if (nq) k_fold_ic_queries<<<nq, WAVE, 0, s->st>>>((infx_cov_query*)s->dCovQ, nq);      // after k_wm: the dictionary lookups take the lower-cased words as they are
     HIPCHK(hipEventRecord(s->evC0, s->st));
     S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
                                                                                  (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 0, (const int32_t*)s->dFPairs);
