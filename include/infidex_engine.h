@@ -63,7 +63,7 @@ int32_t infx_engine_session_last_timings(infx_session* s, double* host_ms5, floa
 /* Where the last batch's planning time went (ms): [0] text preparation + term lookups incl. the LD1 expansion call, [1] of that inside infx_ld1_expand
  * (device work and the wait for it), [2] inside infx_union_build (ditto), [3] idf / roles / device records. */
 int32_t infx_engine_session_plan_breakdown(infx_session* S, double* out4);
-int32_t infx_engine_session_replay_breakdown(infx_session* S, float* ms4 /* k_ex_scan, k_ex_chunk, k_ex_heap, k_exact1 of the last batch */);
+int32_t infx_engine_session_replay_breakdown(infx_session* S, float* ms4 /* scan (k_ex_walk x2 + k_ex_prefix + k_ex_theta), k_ex_chunk, k_ex_heap, k_exact1 of the last batch */);
 int32_t infx_engine_session_last_replay(infx_session* s, float* ms, uint32_t* why3);
 
 /* Document-sharded operation: every rank indexes the whole corpus on the host (global df / avgdl / N), uploads

@@ -262,7 +262,7 @@ struct infx_stream {
     hipEvent_t evTurn = nullptr;                                   // end of this stream's k_select: what the next batch's k_accumulate (another stream) waits for
     hipStream_t stAux = nullptr; hipEvent_t evJoin = nullptr;      // the replay's two k_ex_chunk launches run side by side (both are tail-bound: one wave per chunk)
     hipEvent_t evA0, evA1, evS0, evS1, evC0, evC1, evP0, evP1, evF0, evF1, evX0, evX1, evSync;
-    hipEvent_t evXa, evXb, evXc; bool timedReplayParts = false; float msReplayParts[4] = {0, 0, 0, 0};      // inside the replay: after k_ex_scan, after both k_ex_chunk launches, after k_ex_heap
+    hipEvent_t evXa, evXb, evXc; bool timedReplayParts = false; float msReplayParts[4] = {0, 0, 0, 0};      // inside the replay: after the scan (k_ex_walk x2, k_ex_prefix, k_ex_theta), after the k_ex_chunk launches, after k_ex_heap
     bool timedReplay = false; float msReplay = 0.f; uint32_t lastFlagWhy[4] = {0, 0, 0, 0};     // exact replay of the last batch: kernel time, why its queries were flagged
     // fused pipeline workspaces
     void *dFQ = nullptr, *dFLists = nullptr, *dFOwned = nullptr, *dFS1 = nullptr, *dFMeta = nullptr, *dFQueries = nullptr, *dFKeys = nullptr, *dFScores = nullptr, *dFTies = nullptr, *dFCounts = nullptr, *dFFlags = nullptr, *dFErr = nullptr, *dFHitsAll = nullptr, *dFHcAll = nullptr, *dFPairs = nullptr;
@@ -2088,7 +2088,7 @@ int32_t infx_selftest_div(int32_t device, uint32_t* mismatches) {
     HIPCHK(e1); HIPCHK(e2);
     return INFX_OK;
 }
-int32_t infx_last_replay_breakdown(infx_stream* s, float* ms4) {      // k_ex_scan, k_ex_chunk (both launches), k_ex_heap, k_exact1 of the last batch
+int32_t infx_last_replay_breakdown(infx_stream* s, float* ms4) {      // scan (k_ex_walk x2 + k_ex_prefix + k_ex_theta), k_ex_chunk (three launches), k_ex_heap, k_exact1 of the last batch
     if (!s || !ms4) return fail(INFX_EINVAL, "null argument%s");
     if (s->timedReplayParts) {
         hipEventElapsedTime(&s->msReplayParts[0], s->evX0, s->evXa); hipEventElapsedTime(&s->msReplayParts[1], s->evXa, s->evXb);
