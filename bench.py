@@ -349,7 +349,8 @@ def main():
         if "exact_replays" in t and "stage1_candidates" in t:      # candidate rows of the queries the replay handles, estimated from the flagged share
             t.setdefault("replay_rows", t["stage1_candidates"] * t["exact_replays"] / max(1, args.batch))
     stage_me = {kk: float(np.mean([t[kk] for t in tim if kk in t])) for kk in STAGE_KEYS if any(kk in t for t in tim)}
-    for kk in ("plan_tokens_ms", "plan_ld1_device_ms", "plan_union_device_ms", "plan_finish_ms"):      # where plan_ms went (fused sessions)
+    for kk in ("plan_tokens_ms", "plan_ld1_device_ms", "plan_union_device_ms", "plan_finish_ms",      # where plan_ms went (fused sessions)
+               "plan_exchange_own_slice_ms", "plan_exchange_allgather_ms", "plan_exchange_import_ms"):      # sharded: the plan exchange in front of phase 0 (not part of plan_ms)
         if tim and all(kk in t for t in tim):
             stage_me[kk] = float(np.mean([t[kk] for t in tim]))
     stage_ranks = None
@@ -403,6 +404,9 @@ def main():
         # what every rank issued through the native driver (set-up + warm-up + timed batches): W ranks with equal counts = RCCL saw W ranks in step
         cs = searcher.coll_stats()
         cs["batches"] = len(searcher.sessions) + nsteps
+        # the plan exchange: queries of this rank's last batch planned from exchanged plans (own slice + peers') / imported from peers (W = 1: nothing to exchange)
+        px = searcher.plan_exchange_stats()
+        cs["plan_exchange"] = {"on": bool(searcher.partition_planning), "queries_planned_from_exchange": px[0], "of_them_imported_from_peers": px[1]}
         if dist is not None and world > 1:
             allcs = [None] * world
             dist.all_gather_object(allcs, cs)

@@ -237,15 +237,26 @@ int32_t infx_engine_last_facets(infx_session* s, uint32_t nq, uint32_t qi, uint3
 int32_t infx_engine_prepare_cov_query(infx_engine* e, const uint16_t* q, int32_t len, infx_cov_query* out);
 int32_t infx_sizeof_cov_query(void);
 int32_t infx_engine_effective_cpus(void);
-/* Sharded planning: rank r computes the index-wide host lookups (LD1 expansions, WordMatcher descriptors) for queries [begin, end) of the coming
- * batch; the ranks exchange the serialised results (all-gather of byte blobs) and import each other's before infx_session_phase0.  collect returns
- * the blob size (or -1), blob copies it out, import takes a peer's blob.  Results are identical with or without the exchange. */
+/* Sharded planning — the PLAN EXCHANGE.  Every rank of a document-sharded job answers the same queries and holds the whole host index, and planning is a
+ * pure function of (index, query text): rank r therefore plans queries [begin, end) of the coming batch only — text preparation and term lookups
+ * (VectorModel.cs:376-420), the coverage query context (CoverageEngine.PrepareQuery, CoverageEngine.cs:61-126) and, when the dictionaries are NOT on the device,
+ * the LD1 expansions and WordMatcher descriptors — the ranks exchange the serialised results (one all-gather of byte blobs on a transport of the caller's,
+ * infidex_amd/sharded.py: a gloo group per pipeline session) and import each other's before infx_session_phase0, which then only runs what depends on
+ * the batch as a whole or on this shard (expansion cache, fuzzy unions and their global df, idf / roles, list descriptors).  Per-rank host work per query
+ * goes from the whole plan to 1/W of it plus the import.  collect returns the blob size (or -1) and keeps this rank's own slice, blob copies it out, import
+ * takes a peer's blob (validated: everything in it that reaches the device is range-checked; a plan is only used for the text and depth it was made for).
+ * Results are identical with or without the exchange. */
 int64_t infx_session_prefetch_collect(infx_session* s, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, uint32_t begin, uint32_t end, int32_t depth);
 int32_t infx_session_prefetch_blob(infx_session* s, uint8_t* out, int64_t cap);
 int32_t infx_session_prefetch_import(infx_session* s, const uint8_t* blob, int64_t len);
 int64_t infx_session_prefetch_pending(infx_session* s);        /* imported WordMatcher descriptor sets waiting for the next phase 0 */
+int32_t infx_session_plan_exchange_stats(infx_session* s, uint32_t* out2 /* last phase 0: queries planned from the exchange (own slice + imported), of them imported */);
+/* parity tooling, no device needed: a digest per query of everything the exchange carries for it, from the pending exchange entries where they match the text,
+ * computed locally otherwise (*from_exchange counts the former); entries are not consumed */
+int32_t infx_session_plan_digest(infx_session* s, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, uint64_t* out, uint32_t* from_exchange);
 /* Measurement hook (no device needed): single-threaded host planning cost of a batch by stage, microseconds per query:
- * out_us[0] plan_tokens, [1] of it LD1 walks, [2] plan_finish, [3] wm_collect, [4] prepare_cov_query. */
+ * out_us[0] plan_tokens, [1] of it LD1 walks, [2] plan_finish, [3] wm_collect, [4] prepare_cov_query, [5] plan_tokens_text (the exchangeable share of [0]),
+ * [6] import of the batch's exchanged plans, [7] parsing them in phase 0 (replaces [5] + [4] for an imported query).  out_us holds 8 doubles. */
 int32_t infx_engine_host_plan_profile(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, double* out_us);
 /* Entries of the LD1 expansion cache (least recently used, at most 1000: VectorModel.cs:42). */
 int64_t infx_engine_fuzzy_cache_size(infx_engine* e);

@@ -77,6 +77,16 @@ struct infx_session {
     struct WmPre { std::vector<infx_wm_list> lists; std::vector<int32_t> owned; };
     std::unordered_map<std::u16string, WmPre> wmPre;
     std::vector<uint8_t> prefetchBlob;
+    // plan exchange: per query of the COMING batch, the token-level plan (plan_tokens_text) and the coverage query context (prepare_cov_query) computed by
+    // the rank whose slice holds the query — this rank's own slice included; consumed by the next phase 0 (ph_plan, build_fused_inputs)
+    // Own slice: parsed (plan, cq filled in by the collect).  A peer's: `rec` points at the query's record inside the retained blob (PlanSlab) and is parsed where
+    // the plan is needed — on the planner threads of phase 0, straight into the batch's plan / coverage-query arrays — so the import itself costs a checksum.
+    struct OwnPlan { QueryPlan plan; infx_cov_query cq; };
+    struct PlanPre { uint64_t rawHash = 0; int32_t depth = 0, covErr = 0; bool hasCov = false; const uint8_t* rec = nullptr; uint32_t recLen = 0, covOff = 0; std::unique_ptr<OwnPlan> own; };
+    struct PlanSlab { std::vector<uint8_t> bytes; std::vector<PlanPre> pre; };
+    std::vector<std::shared_ptr<PlanPre>> planPre;
+    uint32_t planFromExchange = 0, planFromPeers = 0;      // last phase 0: queries planned from planPre / of them imported from another rank
+    std::vector<uint8_t> planPeer;                          // planPre[i] came from a peer
 };
 
 struct CompiledFilter { infx_filter* dev = nullptr; uint32_t inFilter = 0; bool counted = false; };
@@ -171,9 +181,69 @@ uint64_t index_fingerprint(const HostIndex& ix) {
 }
 struct BlobW { std::vector<uint8_t>& b; template <class T> void put(const T& v) { const uint8_t* p = (const uint8_t*)&v; b.insert(b.end(), p, p + sizeof(T)); }
                void bytes(const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; b.insert(b.end(), q, q + n); } };
+uint64_t raw_hash(const uint16_t* p, size_t n) {      // FNV-1a over the raw query text: ties an exchanged plan to the query it was made for
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+uint64_t bytes_hash(const uint8_t* p, size_t n) {      // checksum of a blob section: eight bytes per step
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n; size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+    for (; i < n; i++) { h = (h ^ p[i]) * 1099511628211ull; }
+    return h ^ (h >> 29);
+}
 struct BlobR { const uint8_t* p; const uint8_t* e; bool ok = true;
                template <class T> T get() { T v{}; if ((size_t)(e - p) < sizeof(T)) { ok = false; return v; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
                const uint8_t* take(size_t n) { if ((size_t)(e - p) < n) { ok = false; return nullptr; } const uint8_t* r = p; p += n; return r; } };
+// One query's record of the plan exchange (layout: infx_session_prefetch_collect).  parse_plan_record fills the token-level plan and reports where the
+// coverage query sits; parse_cov_record rebuilds the infx_cov_query exactly as prepare_cov_query wrote it (its text is the plan's searchText).
+// Everything that reaches the device is range-checked.  nullptr = fine, else what is wrong.
+const char* parse_plan_record(const HostIndex& ix, const uint8_t* rec, uint32_t len, int depth, QueryPlan& P, bool& hasCov, int32_t& covErr, uint32_t& covOff) {
+    BlobR R{rec, rec + len};
+    auto str = [&](ustr& t) { const uint32_t l = R.get<uint32_t>(); const uint8_t* p = R.take((size_t)l * 2); if (!R.ok) return; t.resize(l); if (l) std::memcpy(&t[0], p, (size_t)l * 2); };
+    P = QueryPlan(); P.depth = depth;
+    R.get<uint64_t>(); const uint8_t fl = R.get<uint8_t>();
+    P.blank = (fl & 1) != 0; P.unsupported = (fl & 2) != 0; hasCov = (fl & 16) != 0; covErr = 0;
+    str(P.qtext); if (fl & 4) P.searchText = P.qtext; else str(P.searchText); if (fl & 8) P.tfidfQuery = P.searchText; else str(P.tfidfQuery);
+    const uint16_t nraw = R.get<uint16_t>();
+    if (!R.ok) return "record truncated";
+    if (nraw > 128) return "more than 128 raw tokens";
+    const int64_t nTerms = (int64_t)ix.terms.K();
+    P.rawTok.resize(nraw);
+    for (uint16_t k = 0; k < nraw && R.ok; k++) {
+        auto& r = P.rawTok[k]; r.id = R.get<int32_t>();
+        if (r.id < 0) { r.id = -1; str(r.text); } else if ((int64_t)r.id >= nTerms) return "term id out of range (ranks must hold the same index)";
+    }
+    if (!R.ok) return "record truncated";
+    covOff = (uint32_t)(R.p - rec);
+    if (hasCov && (fl & 32)) { covErr = R.get<int32_t>(); if (!R.ok || covErr == 0) return "inconsistent coverage-query status"; }
+    return nullptr;
+}
+const char* parse_cov_record(const ustr& searchText, const uint8_t* rec, uint32_t len, uint32_t covOff, infx_cov_query& C) {
+    if (covOff > len) return "record truncated";
+    BlobR R{rec + covOff, rec + len};
+    std::memset(&C, 0, sizeof C);
+    const size_t tl = searchText.size();
+    if (tl > INFX_MAX_QUERY_CHARS) return "coverage query longer than the envelope";
+    std::memcpy(C.text, searchText.data(), tl * 2); C.text_len = (int32_t)tl;
+    C.num_tokens = R.get<int32_t>();
+    if (!R.ok || C.num_tokens < 0 || C.num_tokens > INFX_MAX_QUERY_TOKENS) return "coverage query token count out of range";
+    const size_t nt = (size_t)C.num_tokens; const uint8_t* p;
+    if ((p = R.take(nt * 2))) std::memcpy(C.tok_off, p, nt * 2);
+    if ((p = R.take(nt * 2))) std::memcpy(C.tok_len, p, nt * 2);
+    if ((p = R.take(nt * 4))) std::memcpy(C.term_idf, p, nt * 4);
+    if ((p = R.take(nt * 4))) std::memcpy(C.word_idf, p, nt * 4);
+    C.has_word_idf = R.get<int32_t>(); C.num_fusion_tokens = R.get<int32_t>();
+    if (!R.ok || C.num_fusion_tokens < 0 || C.num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS) return "coverage query token count out of range";
+    const size_t nf = (size_t)C.num_fusion_tokens;
+    if ((p = R.take(nf * 2))) std::memcpy(C.ftok_off, p, nf * 2);
+    if ((p = R.take(nf * 2))) std::memcpy(C.ftok_len, p, nf * 2);
+    C.lcs_tolerance = R.get<int32_t>();
+    if (!R.ok) return "record truncated";
+    for (size_t k = 0; k < nt; k++) if ((size_t)C.tok_off[k] + C.tok_len[k] > tl) return "coverage token outside its text";      // the token tables go to the device
+    for (size_t k = 0; k < nf; k++) if ((size_t)C.ftok_off[k] + C.ftok_len[k] > tl) return "coverage token outside its text";
+    return nullptr;
+}
 }
 
 extern "C" {
@@ -418,9 +488,28 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
     B.t0 = now_ms();
     std::vector<QueryPlan>& plans = S->lastPlans; plans.assign(nq, QueryPlan());
     const bool devLd1 = e->devLookups;      // unknown words are collected per batch; who expands them is decided once their number is known
+    // plan exchange (document shards): the token-level plan of a query may have been made by the rank whose slice holds it (infx_session_prefetch_*);
+    // it is used when it was made for exactly this text and depth, and only the cache / expansion pass runs here
+    const bool havePre = S->planPre.size() == nq;
+    std::atomic<uint32_t> nPre{0}, nPeer{0}; std::atomic<const char*> badRec{nullptr};
     parallel_dyn(nq, threads, devLd1 ? 8 : 1, [&](int64_t b, int64_t en, int) {
-        for (int64_t i = b; i < en; i++) plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, plans[i], false, devLd1);
+        for (int64_t i = b; i < en; i++) {
+            const u16* rp = (const u16*)q_arena + q_offs[i]; const size_t rl = (size_t)(q_offs[i + 1] - q_offs[i]);
+            infx_session::PlanPre* pre = havePre ? S->planPre[i].get() : nullptr;
+            if (pre && pre->depth == depth && pre->rawHash == raw_hash((const uint16_t*)rp, rl)) {
+                // (the entry keeps its coverage query — parsed, or where it sits in the record — for build_fused_inputs)
+                if (pre->rec) { const char* why = parse_plan_record(ix, pre->rec, pre->recLen, depth, plans[i], pre->hasCov, pre->covErr, pre->covOff); if (why) badRec.store(why); }
+                else plans[i] = std::move(pre->own->plan);
+                nPre++; if (S->planPeer[i]) nPeer++;
+            } else {
+                if (havePre) S->planPre[i] = nullptr;      // not this query's: build_fused_inputs must not take its coverage query either
+                plan_tokens_text(ix, uview(rp, rl), depth, plans[i]);
+            }
+            plan_tokens_expand(ix, e->fuzzy, plans[i], false, devLd1);
+        }
     });
+    S->planFromExchange = nPre.load(); S->planFromPeers = nPeer.load();
+    if (badRec.load()) { S->planPre.clear(); S->planPeer.clear(); return efail(INFX_EINVAL, std::string("exchanged plan record: ") + badRec.load()); }
     DevLd1 dl;
     if (devLd1) { int32_t rc = expand_pending(e, S, plans, &dl); if (rc) return rc; }
     B.tTok = now_ms() - B.t0;
@@ -849,7 +938,7 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
         size_t chars = 0; for (uint32_t i = 0; i < nq; i++) chars += plans[i].searchText.size();
         devWm = e->lookups_on_device(0.007 * (double)chars / 7.0);
     }
-    std::atomic<long long> nDev{0}, nHost{0};
+    std::atomic<long long> nDev{0}, nHost{0}; std::atomic<const char*> badRec{nullptr};
     parallel_dyn(nq, threads, 4, [&](int64_t b, int64_t en, int) {
         WmResult wm;
         for (int64_t i = b; i < en; i++) {
@@ -863,7 +952,12 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
             if (isShort) { F.flags |= INFX_FQ_SHORT; int64_t pk = ix.prefixKeys.find(st); int shortCount = pk >= 0 ? (int)ix.prefixPop[pk] : 0; if (shortCount > 500) F.flags |= INFX_FQ_SHORTSKIP; }
             if (!covEnabled || (F.flags & INFX_FQ_SHORTSKIP)) continue;
             F.flags |= INFX_FQ_COV;
-            covErr[i] = prepare_cov_query(ix, st, cq[i]);
+            const infx_session::PlanPre* pp = S->planPre.size() == nq ? S->planPre[i].get() : nullptr;      // (ph_plan dropped the entries that were not made for this batch)
+            if (pp && pp->hasCov) {
+                covErr[i] = pp->covErr;
+                if (!covErr[i] && pp->rec) { if (const char* why = parse_cov_record(st, pp->rec, pp->recLen, pp->covOff, cq[i])) badRec.store(why); }
+                else if (!covErr[i]) cq[i] = pp->own->cq;
+            } else covErr[i] = prepare_cov_query(ix, st, cq[i]);
             if (devWm && !covErr[i] && wm_on_device(ix, st)) { F.flags |= INFX_FQ_WMDEV; nDev++; continue; }      // k_wm resolves the words of cq[i] (lookup.hip.inc)
             auto pre = S->wmPre.find(st);            // computed by a peer rank (sharded planning): same index, same text, same descriptors
             if (pre != S->wmPre.end()) { qLists[i] = pre->second.lists; qOwned[i] = pre->second.owned; }
@@ -871,6 +965,7 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
             nHost++;
         }
     });
+    if (badRec.load()) { S->planPre.clear(); S->planPeer.clear(); return efail(INFX_EINVAL, std::string("exchanged plan record: ") + badRec.load()); }
     // a query outside the Stage-2 envelope (INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS / token length) is answered as "unsupported" (empty result,
     // flag bit 0) — it does not fail the other queries of the batch
     for (uint32_t i = 0; i < nq; i++) if (covErr[i]) { fq[i].flags = INFX_FQ_SKIP | INFX_FQ_UNSUPPORTED; qLists[i].clear(); qOwned[i].clear(); }
@@ -883,7 +978,7 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
         owned.insert(owned.end(), qOwned[i].begin(), qOwned[i].end());
     }
     if (owned.size() > 0xFFFFFFF0ull) return efail(INFX_ECAPACITY, "affix matches of this batch exceed 2^32 ids; split the batch");
-    S->wmPre.clear();
+    S->wmPre.clear(); S->planPre.clear(); S->planPeer.clear();
     return INFX_OK;
 }
 
@@ -1049,27 +1144,39 @@ int32_t infx_session_phase0(infx_session* S, uint32_t nq, const uint16_t* q_aren
 int64_t infx_session_prefetch_collect(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, uint32_t begin, uint32_t end, int32_t depth) {
     if (!S || (nq && (!q_arena || !q_offs)) || begin > end || end > nq) { efail(INFX_EINVAL, "bad arguments"); return -1; }
     infx_engine* e = S->e; const HostIndex& ix = e->ix; const uint32_t n = end - begin;
-    std::vector<QueryPlan> plans(n);
+    // With the dictionaries on the device the two lookups are kernels on every rank's own GPU and sections 1-2 stay empty; section 3 — the
+    // plan exchange — is always there: the host work that is left (text preparation, term lookups, the coverage query context) for this rank's slice only.
+    const bool hostLookups = !e->devLookups;
+    std::vector<std::shared_ptr<infx_session::PlanPre>> pres(n);
     std::vector<std::vector<infx_wm_list>> qL(n); std::vector<std::vector<int32_t>> qO(n);
     parallel_dyn(n, e->threads, 1, [&](int64_t b, int64_t en, int) {
         WmResult wm;
         for (int64_t i = b; i < en; i++) {
             const uint32_t q = begin + (uint32_t)i;
-            plan_tokens(ix, e->fuzzy, uview((const u16*)q_arena + q_offs[q], (size_t)(q_offs[q + 1] - q_offs[q])), depth, plans[i], false);
-            if (!plans[i].blank && !plans[i].unsupported && ix.cfg.enableCoverage) wm_descriptors(ix, plans[i].searchText, wm, qL[i], qO[i]);
+            pres[i] = std::make_shared<infx_session::PlanPre>(); pres[i]->own.reset(new infx_session::OwnPlan); pres[i]->depth = depth;
+            infx_session::PlanPre& R = *pres[i]; QueryPlan& P = R.own->plan;
+            const u16* rp = (const u16*)q_arena + q_offs[q]; const size_t rl = (size_t)(q_offs[q + 1] - q_offs[q]);
+            R.rawHash = raw_hash((const uint16_t*)rp, rl);
+            plan_tokens_text(ix, uview(rp, rl), depth, P);
+            if (hostLookups) plan_tokens_expand(ix, e->fuzzy, P, false);
+            if (!P.blank && !P.unsupported && ix.cfg.enableCoverage) {
+                if (hostLookups) wm_descriptors(ix, P.searchText, wm, qL[i], qO[i]);
+                R.hasCov = true; R.covErr = prepare_cov_query(ix, P.searchText, R.own->cq);
+            }
         }
     });
     std::vector<uint8_t>& blob = S->prefetchBlob; blob.clear(); BlobW W{blob};
     W.put<uint64_t>(index_fingerprint(ix));
     std::map<std::u16string, const FuzzyUnion*> words;          // ordered: the blob is a deterministic function of (index, slice)
-    for (auto& P : plans) for (auto& r : P.rawTok) if (r.fz) words.emplace(r.text, r.fz.get());
+    for (auto& R : pres) for (auto& r : R->own->plan.rawTok) if (r.fz) words.emplace(r.text, r.fz.get());
     W.put<uint32_t>((uint32_t)words.size());
     for (auto& kv : words) {
         W.put<uint16_t>((uint16_t)kv.first.size()); W.bytes(kv.first.data(), kv.first.size() * 2);
         W.put<uint32_t>((uint32_t)kv.second->members.size()); W.bytes(kv.second->members.data(), kv.second->members.size() * 4);
     }
     std::map<std::u16string, uint32_t> texts;
-    for (uint32_t i = 0; i < n; i++) if (!plans[i].blank && !plans[i].unsupported && ix.cfg.enableCoverage && plans[i].searchText.size() <= 0xFFFF) texts.emplace(plans[i].searchText, i);
+    if (hostLookups)
+        for (uint32_t i = 0; i < n; i++) { const QueryPlan& P = pres[i]->own->plan; if (!P.blank && !P.unsupported && ix.cfg.enableCoverage && P.searchText.size() <= 0xFFFF) texts.emplace(P.searchText, i); }
     W.put<uint32_t>((uint32_t)texts.size());
     for (auto& kv : texts) {
         const uint32_t i = kv.second;
@@ -1077,6 +1184,43 @@ int64_t infx_session_prefetch_collect(infx_session* S, uint32_t nq, const uint16
         W.put<uint32_t>((uint32_t)qL[i].size());
         for (auto& L : qL[i]) { W.put<uint32_t>(L.src); W.put<uint32_t>(L.len); W.put<uint64_t>(L.off); }
         W.put<uint32_t>((uint32_t)qO[i].size()); W.bytes(qO[i].data(), qO[i].size() * 4);
+    }
+    // section 3, the plan exchange: u32 begin, end, nq; i32 depth; per query of the slice
+    //   (table of n + 1 u32 record offsets first, so that an importer can find a record without parsing the ones before it)
+    //   u64 hash of the raw text; u8 flags (1 blank, 2 unsupported, 4 searchText == qtext, 8 tfidfQuery == searchText, 16 coverage query present, 32 .. outside the envelope)
+    //   str qtext; [str searchText]; [str tfidfQuery]; u16 nraw { i32 id; [str text] }*       (str = u32 length + UTF-16 units; unknown words drop their expansion:
+    //   the importer looks them up in ITS cache / expands them with the batch, as for its own queries)
+    //   coverage query (its text is searchText): i32 status | i32 num_tokens, u16 tok_off[], u16 tok_len[], f32 term_idf[], f32 word_idf[], i32 has_word_idf,
+    //   i32 num_fusion_tokens, u16 ftok_off[], u16 ftok_len[], i32 lcs_tolerance
+    auto str = [&](const ustr& t) { W.put<uint32_t>((uint32_t)t.size()); W.bytes(t.data(), t.size() * 2); };
+    const size_t sec3 = blob.size();
+    W.put<uint32_t>(begin); W.put<uint32_t>(end); W.put<uint32_t>(nq); W.put<int32_t>(depth);
+    const size_t tab = blob.size(); blob.resize(tab + ((size_t)n + 1) * 4);      // u32 record offsets (n + 1), relative to the first record
+    const size_t rec0 = blob.size();
+    auto tabput = [&](uint32_t k) { const uint32_t o = (uint32_t)(blob.size() - rec0); std::memcpy(blob.data() + tab + (size_t)k * 4, &o, 4); };
+    for (uint32_t i = 0; i < n; i++) {
+        tabput(i);
+        const infx_session::PlanPre& R = *pres[i]; const QueryPlan& P = R.own->plan;
+        const bool sameST = P.searchText == P.qtext, sameTQ = P.tfidfQuery == P.searchText;
+        W.put<uint64_t>(R.rawHash);
+        W.put<uint8_t>((uint8_t)((P.blank ? 1 : 0) | (P.unsupported ? 2 : 0) | (sameST ? 4 : 0) | (sameTQ ? 8 : 0) | (R.hasCov ? 16 : 0) | (R.covErr ? 32 : 0)));
+        str(P.qtext); if (!sameST) str(P.searchText); if (!sameTQ) str(P.tfidfQuery);
+        W.put<uint16_t>((uint16_t)P.rawTok.size());
+        for (auto& r : P.rawTok) { W.put<int32_t>(r.id); if (r.id < 0) str(r.text); }
+        if (R.hasCov && R.covErr) W.put<int32_t>(R.covErr);
+        else if (R.hasCov) {
+            const infx_cov_query& C = R.own->cq; const size_t nt = (size_t)C.num_tokens, nf = (size_t)C.num_fusion_tokens;
+            W.put<int32_t>(C.num_tokens); W.bytes(C.tok_off, nt * 2); W.bytes(C.tok_len, nt * 2); W.bytes(C.term_idf, nt * 4); W.bytes(C.word_idf, nt * 4);
+            W.put<int32_t>(C.has_word_idf); W.put<int32_t>(C.num_fusion_tokens); W.bytes(C.ftok_off, nf * 2); W.bytes(C.ftok_len, nf * 2); W.put<int32_t>(C.lcs_tolerance);
+        }
+    }
+    tabput(n);
+    W.put<uint64_t>(bytes_hash(blob.data() + sec3, blob.size() - sec3));      // the section's checksum: plans steer kernels, a damaged one must not be believed
+    // this rank's own slice needs no round trip
+    S->planPre.assign(nq, nullptr); S->planPeer.assign(nq, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        for (auto& r : pres[i]->own->plan.rawTok) { r.fz = nullptr; r.pending = false; }      // phase 0 resolves them against the cache as it stands then
+        S->planPre[begin + i] = std::move(pres[i]);
     }
     return (int64_t)blob.size();
 }
@@ -1120,6 +1264,67 @@ int32_t infx_session_prefetch_import(infx_session* S, const uint8_t* blob, int64
         S->wmPre.emplace(std::move(text), std::move(pre));
     }
     if (!R.ok) return efail(INFX_EINVAL, "prefetch blob truncated");
+    // section 3: the peer's slice of the batch's plans
+    if ((size_t)(R.e - R.p) < 24 || [&] { uint64_t want; std::memcpy(&want, R.e - 8, 8); return want != bytes_hash(R.p, (size_t)(R.e - R.p) - 8); }())
+        return efail(INFX_EINVAL, "prefetch blob: plan section damaged (checksum)");
+    R.e -= 8;
+    const uint32_t begin = R.get<uint32_t>(), end = R.get<uint32_t>(), bnq = R.get<uint32_t>(); const int32_t depth = R.get<int32_t>();
+    if (!R.ok || begin > end || end > bnq) return efail(INFX_EINVAL, "prefetch blob: plan section truncated or its slice is out of range");
+    const uint32_t n = end - begin;
+    const uint8_t* offp = R.take(((size_t)n + 1) * 4);
+    if (!offp) return efail(INFX_EINVAL, "prefetch blob truncated");
+    // the records stay in a copy of the section; each query's entry points at its record, which phase 0 parses on its planner threads
+    auto slab = std::make_shared<infx_session::PlanSlab>();
+    slab->bytes.assign(R.p, R.e); slab->pre.resize(n);
+    const size_t total = slab->bytes.size();
+    std::vector<uint32_t> offs((size_t)n + 1); std::memcpy(offs.data(), offp, ((size_t)n + 1) * 4);
+    if (offs[0] != 0 || offs[n] != total) return efail(INFX_EINVAL, "prefetch blob: plan record table does not match the section");
+    for (uint32_t k = 0; k < n; k++) {
+        if (offs[k + 1] < offs[k] || offs[k + 1] > total || offs[k + 1] - offs[k] < 9) return efail(INFX_EINVAL, "prefetch blob: plan record table does not match the section");
+        infx_session::PlanPre& E = slab->pre[k];
+        E.rec = slab->bytes.data() + offs[k]; E.recLen = offs[k + 1] - offs[k]; E.depth = depth;
+        std::memcpy(&E.rawHash, E.rec, 8);
+    }
+    if (S->planPre.size() != bnq) { S->planPre.assign(bnq, nullptr); S->planPeer.assign(bnq, 0); }
+    for (uint32_t k = 0; k < n; k++) { S->planPre[begin + k] = std::shared_ptr<infx_session::PlanPre>(slab, &slab->pre[k]); S->planPeer[begin + k] = 1; }
+    return INFX_OK;
+}
+// Plan exchange, observed: out2 = {queries of the last phase 0 whose token-level plan came through infx_session_prefetch_* (own slice + imported), of them imported from peers}
+int32_t infx_session_plan_exchange_stats(infx_session* S, uint32_t* out2) {
+    if (!S || !out2) return efail(INFX_EINVAL, "null");
+    out2[0] = S->planFromExchange; out2[1] = S->planFromPeers; return INFX_OK;
+}
+// Parity tooling (no device needed): one 64-bit digest per query of everything the plan exchange carries — flags, the three texts, the raw tokens, the coverage
+// query context byte for byte — taken from the session's pending exchange entries where they exist and match the text, computed here otherwise; *from_exchange
+// counts the former.  Equal digests with and without an exchange = the exchange changes nothing.  Does not consume the entries.
+int32_t infx_session_plan_digest(infx_session* S, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, uint64_t* out, uint32_t* from_exchange) {
+    if (!S || !out || (nq && (!q_arena || !q_offs))) return efail(INFX_EINVAL, "bad arguments");
+    const HostIndex& ix = S->e->ix; uint32_t used = 0;
+    for (uint32_t i = 0; i < nq; i++) {
+        const u16* rp = (const u16*)q_arena + q_offs[i]; const size_t rl = (size_t)(q_offs[i + 1] - q_offs[i]);
+        infx_session::PlanPre local; local.own.reset(new infx_session::OwnPlan); const infx_session::PlanPre* R = S->planPre.size() == nq ? S->planPre[i].get() : nullptr;
+        if (R && R->depth == depth && R->rawHash == raw_hash((const uint16_t*)rp, rl)) {
+            used++;
+            if (R->rec) {      // a peer's record: parsed here as phase 0 would
+                const char* why = parse_plan_record(ix, R->rec, R->recLen, depth, local.own->plan, local.hasCov, local.covErr, local.covOff);
+                if (!why && local.hasCov && !local.covErr) why = parse_cov_record(local.own->plan.searchText, R->rec, R->recLen, local.covOff, local.own->cq);
+                if (why) return efail(INFX_EINVAL, std::string("exchanged plan record: ") + why);
+                R = &local;
+            }
+        } else {
+            plan_tokens_text(ix, uview(rp, rl), depth, local.own->plan);
+            if (!local.own->plan.blank && !local.own->plan.unsupported && ix.cfg.enableCoverage) { local.hasCov = true; local.covErr = prepare_cov_query(ix, local.own->plan.searchText, local.own->cq); }
+            R = &local;
+        }
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 1099511628211ull; } const uint64_t nn = n; for (int k = 0; k < 8; k++) { h ^= (nn >> (8 * k)) & 0xFF; h *= 1099511628211ull; } };
+        const QueryPlan& P = R->own->plan; const uint8_t fl = (uint8_t)((P.blank ? 1 : 0) | (P.unsupported ? 2 : 0) | (R->hasCov ? 4 : 0)); const int32_t d = P.depth;
+        mix(&fl, 1); mix(&d, 4); mix(P.qtext.data(), P.qtext.size() * 2); mix(P.searchText.data(), P.searchText.size() * 2); mix(P.tfidfQuery.data(), P.tfidfQuery.size() * 2);
+        for (auto& r : P.rawTok) { mix(&r.id, 4); mix(r.text.data(), r.text.size() * 2); }
+        if (R->hasCov) { mix(&R->covErr, 4); if (!R->covErr) mix(&R->own->cq, sizeof R->own->cq); }
+        out[i] = h;
+    }
+    if (from_exchange) *from_exchange = used;
     return INFX_OK;
 }
 int32_t infx_session_union_counts(infx_session* S, uint32_t* counts) {   // this shard's |union| of every pending fuzzy virtual term
@@ -1552,7 +1757,9 @@ int32_t infx_engine_plan(infx_engine* e, const uint16_t* q, int32_t len, int32_t
 }
 // Host planning profile (measurement hook, no device needed): the per-query host work of a batch, single-threaded, by stage, in microseconds
 // per query: [0] plan_tokens (text preparation, term lookups, LD1 expansion), [1] of that: LD1 walks, [2] plan_finish (idf, roles, modes),
-// [3] wm_collect (WordMatcher descriptors), [4] prepare_cov_query.  Pending fuzzy unions get a stand-in df (their member count).
+// [3] wm_collect (WordMatcher descriptors), [4] prepare_cov_query, [5] plan_tokens_text (the share of [0] that the plan exchange moves to the slice's owner),
+// [6] import of the batch's exchanged plans (with host lookups also the LD1 member lists and WordMatcher descriptors), [7] parsing the imported records in
+// phase 0 (what an imported query costs there instead of [5] + [4]).  Pending fuzzy unions get a stand-in df.
 int32_t infx_engine_host_plan_profile(infx_engine* e, uint32_t nq, const uint16_t* q_arena, const uint64_t* q_offs, int32_t depth, double* out_us) {
     if (!e || !out_us || (nq && (!q_arena || !q_offs))) return efail(INFX_EINVAL, "null argument");
     const HostIndex& ix = e->ix; FuzzyCache fc;
@@ -1570,7 +1777,29 @@ int32_t infx_engine_host_plan_profile(infx_engine* e, uint32_t nq, const uint16_
     infx_cov_query cq;
     for (uint32_t i = 0; i < nq; i++) { const QueryPlan& P = plans[i]; if (P.blank || P.unsupported) continue; sink += (size_t)prepare_cov_query(ix, P.searchText, cq); }
     auto t5 = std::chrono::steady_clock::now();
+    // the plan exchange: [5] the part of plan_tokens a peer can do (plan_tokens_text: no cache, no expansion), [6] importing a peer's plans (the whole batch as one slice)
+    { QueryPlan tmp; for (uint32_t i = 0; i < nq; i++) { plan_tokens_text(ix, uview((const u16*)q_arena + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i])), depth, tmp); sink += tmp.rawTok.size(); } }
+    auto t6 = std::chrono::steady_clock::now();
+    auto t7 = t6, t8 = t6, t9 = t6;
+    const bool dl = e->devLookups; e->devLookups = true;      // the blob of the deployment this hook is about: dictionaries on the device, the plan section only
+    const int64_t blobBytes = e->def ? infx_session_prefetch_collect(e->def, nq, q_arena, q_offs, 0, nq, depth) : -1;
+    e->devLookups = dl;
+    if (blobBytes >= 0) {
+        std::vector<uint8_t> blob = e->def->prefetchBlob;
+        e->def->planPre.clear(); e->def->planPeer.clear();      // (a peer's slice never overlaps the own one)
+        t7 = std::chrono::steady_clock::now();
+        const int32_t rc = infx_session_prefetch_import(e->def, blob.data(), (int64_t)blob.size());
+        t8 = std::chrono::steady_clock::now();
+        if (!rc) {      // [7]: what phase 0 then pays per imported query instead of [5] + [4]: parsing the record into the plan and the coverage query
+            QueryPlan tmp; infx_cov_query tc; bool hc; int32_t ce; uint32_t co;
+            for (auto& pp : e->def->planPre) if (pp && pp->rec && !parse_plan_record(ix, pp->rec, pp->recLen, depth, tmp, hc, ce, co) && hc && !ce) sink += parse_cov_record(tmp.searchText, pp->rec, pp->recLen, co, tc) ? 1 : 0;
+        }
+        t9 = std::chrono::steady_clock::now();
+        e->def->planPre.clear(); e->def->planPeer.clear(); e->def->wmPre.clear();
+        if (rc) return rc;
+    }
     auto us = [&](auto a, auto b) { return std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3 / std::max<uint32_t>(1, nq); };
+    out_us[5] = us(t5, t6); out_us[6] = us(t7, t8); out_us[7] = us(t8, t9);
     out_us[0] = us(t0, t1); out_us[1] = fc.ld1Ns.load() / 1e3 / std::max<uint32_t>(1, nq); out_us[2] = us(t2, t3); out_us[3] = us(t3, t4); out_us[4] = us(t4, t5) + (sink == (size_t)-1 ? 1 : 0);
     return INFX_OK;
 }

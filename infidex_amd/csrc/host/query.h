@@ -280,11 +280,9 @@ inline void analyze_query(uview text, int minIndexSize, bool& canUse, bool& mixe
     if (shortCnt > 0 && longCnt > 0) mixed = true;
 }
 
-// Pass 1: text preparation, term lookup, LD1 member lists of unknown words (df of new unions still pending).
-// hostUnions: build the unions on the host (engines without a device: planning introspection only).
-// deferLd1: an unknown word the expansion cache does not hold is only marked `pending`; the caller expands the distinct pending words of the whole
-// batch at once (ph_plan: on the device, infx_ld1_expand) and fills in `fz`.
-inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int depth, QueryPlan& P, bool hostUnions, bool deferLd1 = false) {
+// Pass 1a: text preparation and term lookup — a pure function of (index, raw query text): no cache, no device.  Under document sharding rank r runs it
+// for its slice of a batch only and the ranks exchange the results (infx_session_prefetch_*: the plan exchange).
+inline void plan_tokens_text(const HostIndex& ix, uview raw, int depth, QueryPlan& P) {
     P = QueryPlan(); P.depth = depth;
     size_t b = 0, e = raw.size();
     while (b < e && is_ws(raw[b])) b++;
@@ -315,8 +313,14 @@ inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
         }
     std::sort(rawTok.begin(), rawTok.end(), [](const Raw& a, const Raw& c) { return a.id != c.id ? a.id < c.id : a.text < c.text; });
     rawTok.erase(std::unique(rawTok.begin(), rawTok.end(), [](const Raw& a, const Raw& c) { return a.id == c.id && a.text == c.text; }), rawTok.end());
-
-    for (auto& r : rawTok) {
+}
+// Pass 1b: LD1 member lists of the unknown words (df of new unions still pending) — expansion cache first.
+// hostUnions: build the unions on the host (engines without a device: planning introspection only).
+// deferLd1: an unknown word the expansion cache does not hold is only marked `pending`; the caller expands the distinct pending words of the whole
+// batch at once (ph_plan: on the device, infx_ld1_expand) and fills in `fz`.
+inline void plan_tokens_expand(const HostIndex& ix, FuzzyCache& fc, QueryPlan& P, bool hostUnions, bool deferLd1 = false) {
+    if (P.blank || P.unsupported) return;
+    for (auto& r : P.rawTok) {
         if (r.id >= 0 || r.text.size() < 4) continue;      // ExpandMissingTerm (VectorModel.cs:643-743): unknown words of length >= 4
         auto fz = fc.get(r.text);
         if (!fz && deferLd1) { r.pending = true; continue; }
@@ -334,6 +338,10 @@ inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int dept
         }
         r.fz = fz;
     }
+}
+inline void plan_tokens(const HostIndex& ix, FuzzyCache& fc, uview raw, int depth, QueryPlan& P, bool hostUnions, bool deferLd1 = false) {
+    plan_tokens_text(ix, raw, depth, P);
+    plan_tokens_expand(ix, fc, P, hostUnions, deferLd1);
 }
 
 // Pass 2 (every union's df known): idf / maxScore, candidate-selection mode and tier roles.

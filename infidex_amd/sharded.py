@@ -458,8 +458,10 @@ class ShardedSearcher:
         import os
         self.native = (os.environ.get("INFX_SHARD_NATIVE", "1") != "0") if native is None else bool(native)
         self.comm = comm
-        # with the dictionaries on the device (the default) the expensive lookups are kernels on every rank's own GPU: nothing is left to partition
-        self.partition_planning = partition_planning and comm.world > 1 and not engine.device_lookups()
+        # the plan exchange: rank r plans its 1/W slice of every batch, the ranks all-gather the plans (INFX_PLAN_EXCHANGE=0 or partition_planning=False:
+        # every rank plans every query).  With the dictionaries on the device (the default) the blobs carry the token-level plans and the
+        # coverage query contexts; with host lookups also the LD1 expansions and the WordMatcher descriptors.
+        self.partition_planning = partition_planning and comm.world > 1 and os.environ.get("INFX_PLAN_EXCHANGE", "1") != "0"
         K = max(1, int(sessions)) if self.native else 1
         self.sessions = [ShardSession(engine) for _ in range(K)]
         self.sess = self.sessions[0]
@@ -471,25 +473,32 @@ class ShardedSearcher:
             if self.native:
                 cc, keep = native_comm(engine, comm, session=s, group=(comm.dist.new_group(backend="gloo") if gloo and K > 1 else None))
                 self.ccomms.append(cc); self._keep.append(keep)
-            self.plan_groups.append(comm.dist.new_group(backend="gloo") if self.partition_planning else None)
+            self.plan_groups.append(comm.dist.new_group(backend="gloo") if self.partition_planning else None)      # (collective: every rank creates the same groups in the same order)
         self.plan_group = self.plan_groups[0]
         on_dev = comm.device.type == "cuda" and comm.dist.get_backend() == "nccl"
         self.X = _DistX(comm, _DevBufs(comm.device) if on_dev else _HostBufs())
         self.in_filter = 0
 
     def _prefetch(self, k, arena, offs, depth):
-        """Sharded planning: this rank runs the expensive index-wide host lookups (LD1 expansion of unknown words, WordMatcher descriptors —
-        ~85 % of the host time per query at 10 M documents) for its 1/W slice of the batch only; the ranks all-gather the results and import
-        each other's before phase 0.  Results are unchanged: every rank holds the whole host index, the lookups are pure functions of the text."""
+        """Plan exchange: this rank plans its 1/W slice of the batch only (text preparation, term lookups, coverage query contexts; with host
+        lookups also the LD1 expansions and WordMatcher descriptors); the ranks all-gather the results and import each other's before phase 0.
+        Results are unchanged: every rank holds the whole host index, and what is exchanged is a pure function of (index, query text)."""
+        import time
         c = self.comm; s = self.sessions[k]
+        s.plan_exchange_ms = (0.0, 0.0, 0.0)
         if c.world <= 1 or not self.partition_planning:
             return
         nq = len(offs) - 1
         begin, end = nq * c.rank // c.world, nq * (c.rank + 1) // c.world
+        t0 = time.time()
         mine = s.prefetch_collect(arena, offs, begin, end, depth)
-        for r, b in enumerate(c.allgather_bytes(mine, group=self.plan_groups[k])):
+        t1 = time.time()
+        blobs = c.allgather_bytes(mine, group=self.plan_groups[k])
+        t2 = time.time()
+        for r, b in enumerate(blobs):
             if r != c.rank and b.size:
                 s.prefetch_import(b)
+        s.plan_exchange_ms = (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (time.time() - t2))      # planning the own slice, all-gather (incl. waiting for the peers), import
 
     def _one(self, k, arena, offs, max_results, depth, enable_coverage):
         s = self.sessions[k]
@@ -512,6 +521,12 @@ class ShardedSearcher:
             return
         hs = (C.c_void_p * max(1, n))(*[self.sessions[k].s.h for k in range(n)])
         self.sessions[0].e._check(self.sessions[0].L.infx_engine_coll_ring(self.sessions[0].e.h, n, hs))
+
+    def plan_exchange_stats(self, k=None):
+        """(queries of session k's last phase 0 planned from the exchange, of them imported from peers); k = None: the last session used."""
+        s = self.last if k is None else self.sessions[k]
+        o = np.zeros(2, np.uint32); s.e._check(s.L.infx_session_plan_exchange_stats(s.s.h, _p(o, C.c_uint32)))
+        return int(o[0]), int(o[1])
 
     def coll_stats(self):
         """Collectives this rank issued through the native driver so far: calls and payload bytes, summed over the pipeline sessions."""
@@ -541,6 +556,8 @@ class ShardedSearcher:
                     t0 = time.time()
                     out[i] = self._one(k, batches[i][0], batches[i][1], max_results, depth, enable_coverage)
                     st[i] = (t0, time.time()); tm[i] = self.sessions[k].s.last_timings()
+                    px = getattr(self.sessions[k], "plan_exchange_ms", (0.0, 0.0, 0.0))
+                    tm[i]["plan_exchange_own_slice_ms"], tm[i]["plan_exchange_allgather_ms"], tm[i]["plan_exchange_import_ms"] = px
                     done[i].set()
             except Exception as ex:      # surfaced by the consumer
                 err.append(ex)

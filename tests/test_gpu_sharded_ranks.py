@@ -31,9 +31,12 @@ a, o = pack_texts(texts)
 batches = [(a, o), pack_texts(texts[:100]), pack_texts(texts[100:])]
 res = list(searcher.search_stream(batches, 20, 500))             # three batches in flight: a session, a stream and a communicator each
 single = searcher.search_packed(a, o, 20, 500)
-# sharded planning on (default: each rank runs the LD1 / WordMatcher host lookups for its half of the batch, blobs exchanged on the planning group)
-# and off (every rank plans the whole batch) must agree
-assert eng.device_lookups() and not searcher.partition_planning and searcher.native and len(searcher.sessions) == 3      # dictionaries on the device: nothing to partition
+# plan exchange on (default: each rank plans its half of the batch — text preparation, term lookups, coverage query contexts — and the blobs are exchanged
+# on the planning group) and off (every rank plans the whole batch) must agree
+assert eng.device_lookups() and searcher.partition_planning and searcher.native and len(searcher.sessions) == 3
+used, peers = searcher.plan_exchange_stats()
+nq_ = len(o) - 1; mine_ = nq_ * (rank + 1) // world - nq_ * rank // world
+assert used == nq_ and peers == nq_ - mine_, (used, peers, nq_, mine_)      # every plan of the last batch came through the exchange, the peer's half from its blob
 off = ShardedSearcher(eng, TorchComm(dist), partition_planning=False, native=False)      # Python-driven phases, every rank plans the whole batch
 r_off = off.search_packed(a, o, 20, 500)
 for x, y in zip(single, r_off):
@@ -86,4 +89,6 @@ def test_bench_gpus_2():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     cs = d["collectives_per_rank"]
+    px = [c.pop("plan_exchange") for c in cs]
     assert len(cs) == 2 and cs[0] == cs[1], cs
+    assert all(p["on"] and p["queries_planned_from_exchange"] == 200 and p["of_them_imported_from_peers"] == 100 for p in px), px      # each rank planned half of the last batch

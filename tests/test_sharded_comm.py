@@ -79,7 +79,11 @@ def _prefetch_worker(rank, world, port, q):
     from tools.synth import Synth
     s = Synth(4, docs=30000); arena, offs = s.docs()
     e = SearchEngine.create_default(device=-1); e.index_flat(None, arena, offs, s.field_weights)
+    from infidex_amd.engine import pack_texts
+    # blank, short ("unsupported"), beyond the Stage-2 envelope (too long / too many distinct words), outside the BMP: every kind of plan record crosses
+    extras = ["", "   ", "qu", "x" * 600, " ".join("w%dq" % i for i in range(40)), "caf\u00e9 \U0001F50D na\u00efve", "ab cd ef"]
     qa, qo = s.queries(200, qseed=5, fuzz=0.6)
+    qa, qo = pack_texts(Synth.texts(qa, qo) + extras)
     nq = len(qo) - 1
     sess = C.c_void_p(); assert e.L.infx_engine_default_session(e.h, C.byref(sess)) == 0
     L = e.L; L.infx_session_prefetch_collect.restype = C.c_int64; L.infx_session_prefetch_pending.restype = C.c_int64
@@ -88,6 +92,11 @@ def _prefetch_worker(rank, world, port, q):
         n = L.infx_session_prefetch_collect(sess, nq, _p(qa, C.c_uint16), _p(qo, C.c_uint64), b, en, 500); assert n >= 8
         blob = np.zeros(n, np.uint8); assert L.infx_session_prefetch_blob(sess, _p(blob, C.c_uint8), C.c_int64(n)) == 0
         return blob
+    def digest():
+        out = np.zeros(nq, np.uint64); used = C.c_uint32(0)
+        assert L.infx_session_plan_digest(sess, nq, _p(qa, C.c_uint16), _p(qo, C.c_uint64), 500, _p(out, C.c_uint64), C.byref(used)) == 0
+        return out, int(used.value)
+    d_self, used_self = digest()                                   # every query planned here
     c = TorchComm(dist); g = c.planning_group()
     begin, end = nq * rank // world, nq * (rank + 1) // world
     mine = collect(begin, end)
@@ -97,9 +106,21 @@ def _prefetch_worker(rank, world, port, q):
         if r != rank:
             assert L.infx_session_prefetch_import(sess, _p(np.ascontiguousarray(b), C.c_uint8), C.c_int64(b.size)) == 0
     pending = int(L.infx_session_prefetch_pending(sess))
-    # a truncated blob is rejected, not half-imported silently
+    d_x, used_x = digest()                                         # own slice from the collect, the peer's slice from its blob
+    # another batch (other texts, same size): the pending entries are not believed
+    qa2, qo2 = s.queries(200, qseed=6, fuzz=0.6)
+    qa2, qo2 = pack_texts(Synth.texts(qa2, qo2) + extras)
+    out2 = np.zeros(nq, np.uint64); used2 = C.c_uint32(7)
+    assert L.infx_session_plan_digest(sess, nq, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), 500, _p(out2, C.c_uint64), C.byref(used2)) == 0
+    same_text = sum(1 for i in range(nq) if np.array_equal(qa[qo[i]:qo[i + 1]], qa2[qo2[i]:qo2[i + 1]]))
+    # a truncated blob is rejected, not half-imported silently; so is one with a flipped bit in the plan section (checksum)
     bad = np.ascontiguousarray(blobs[1 - rank][: max(9, blobs[1 - rank].size // 2)])
     rc_bad = L.infx_session_prefetch_import(sess, _p(bad, C.c_uint8), C.c_int64(bad.size))
+    flip = np.ascontiguousarray(blobs[1 - rank]).copy(); flip[flip.size - 40] ^= 4
+    rc_flip = L.infx_session_prefetch_import(sess, _p(flip, C.c_uint8), C.c_int64(flip.size))
+    d_after, used_after = digest()                                 # the refused imports left the entries alone
+    assert np.array_equal(d_self, d_x) and np.array_equal(d_self, d_after), "plans through the exchange differ from the plans made here"
+    assert used_self == 0 and used_x == nq and used_after == nq and int(used2.value) == same_text and rc_flip != 0, (used_self, used_x, used_after, int(used2.value), same_text, rc_flip)
     # the peer's slice, recomputed here after the import (LD1 expansions now come from the fuzzy cache): byte-identical to what the peer sent
     ob, oe = nq * (1 - rank) // world, nq * (2 - rank) // world
     again = collect(ob, oe)
