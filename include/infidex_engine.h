@@ -236,6 +236,10 @@ int32_t infx_engine_last_facets(infx_session* s, uint32_t nq, uint32_t qi, uint3
  * (infx_stage2_batch) prepare Stage-2 inputs without the engine's search path. */
 int32_t infx_engine_prepare_cov_query(infx_engine* e, const uint16_t* q, int32_t len, infx_cov_query* out);
 int32_t infx_sizeof_cov_query(void);
+/* the same for a query beyond the fast Stage-2 envelope (infx_engine_prepare_cov_query returns INFX_EUNSUPPORTED for it): the record of the long-query table
+ * (infx_stage2_long_queries, include/infidex_hip.h) */
+int32_t infx_engine_prepare_cov_query_long(infx_engine* e, const uint16_t* q, int32_t len, infx_cov_query_long* out);
+int32_t infx_sizeof_cov_query_long(void);
 int32_t infx_engine_effective_cpus(void);
 /* Sharded planning — the PLAN EXCHANGE.  Every rank of a document-sharded job answers the same queries and holds the whole host index, and planning is a
  * pure function of (index, query text): rank r therefore plans queries [begin, end) of the coming batch only — text preparation and term lookups

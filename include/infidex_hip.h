@@ -33,8 +33,10 @@ extern "C" {
 #define INFX_ENCCL         6   /* RCCL error (or librccl could not be loaded) */
 
 #define INFX_MAX_QUERY_TERMS   128  /* VectorModel.cs:381 rents 128 raw tokens */
-#define INFX_MAX_QUERY_TOKENS  32   /* Stage-2 query words after dedupe */
+#define INFX_MAX_QUERY_TOKENS  32   /* Stage-2 query words after dedupe: the fast envelope (infx_cov_query) */
 #define INFX_MAX_QUERY_CHARS   512
+#define INFX_LONGQ_TOKENS      128  /* the long envelope (infx_cov_query_long): queries beyond the fast one take k_stage2's long-query launches — slower, same results */
+#define INFX_LONGQ_CHARS       2048
 #define INFX_MAX_DOC_TOKENS    192  /* Stage-2 words per document text handled in registers / scratch; longer texts (the reference allows 65 535 characters,
                                        Api/DocumentFields.cs:140) take k_stage2's global-workspace pass: slower, same results */
 #define INFX_NFEAT             32   /* ints per infx_cov_out.feat */
@@ -191,8 +193,26 @@ typedef struct infx_cov_query {
     uint16_t ftok_off[INFX_MAX_QUERY_TOKENS * 2];
     uint16_t ftok_len[INFX_MAX_QUERY_TOKENS * 2];
     int32_t  lcs_tolerance;                       /* SearchPipeline.cs:498-500 */
-    int32_t  reserved;
+    int32_t  reserved;                            /* 0, or 1 + the index of this query's record in the stream's long-query table (infx_stage2_long_queries): the
+                                                     query is beyond the fast envelope, lives there, and the other members of this struct are ignored */
 } infx_cov_query;
+/* The same context for a query beyond INFX_MAX_QUERY_TOKENS distinct words / INFX_MAX_QUERY_CHARS characters (the reference has no limit: PrepareQuery rents
+ * query.Length / 2 + 1 token slots, CoverageEngine.cs:68): up to INFX_LONGQ_TOKENS / INFX_LONGQ_CHARS.  Same members, larger tables. */
+typedef struct infx_cov_query_long {
+    uint16_t text[INFX_LONGQ_CHARS];
+    int32_t  text_len;
+    int32_t  num_tokens;
+    uint16_t tok_off[INFX_LONGQ_TOKENS];
+    uint16_t tok_len[INFX_LONGQ_TOKENS];
+    float    term_idf[INFX_LONGQ_TOKENS];
+    float    word_idf[INFX_LONGQ_TOKENS];
+    int32_t  has_word_idf;
+    int32_t  num_fusion_tokens;
+    uint16_t ftok_off[INFX_LONGQ_TOKENS * 2];
+    uint16_t ftok_len[INFX_LONGQ_TOKENS * 2];
+    int32_t  lcs_tolerance;
+    int32_t  reserved;
+} infx_cov_query_long;
 
 typedef struct infx_cov_cand {
     uint32_t query;        /* index into the batch's infx_cov_query[] */
@@ -212,6 +232,9 @@ typedef struct infx_cov_out {
 
 /* feat_out (may be NULL): ncand x INFX_NFEAT ints — CoverageFeatures / FusionSignals (the bit-exact parity target; the
  * reference keeps them internal, Coverage/CoverageFeatures.cs:3-88), layout in DESIGN.md. */
+/* Long queries of the NEXT Stage-2 call on this stream (infx_stage2_batch, infx_search_fused, infx_shard_stage2): n records, referred to by
+ * infx_cov_query.reserved = 1 + index.  The table is consumed by that call; n = 0 clears it. */
+int32_t infx_stage2_long_queries(infx_stream* s, uint32_t n, const infx_cov_query_long* q);
 int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, uint32_t ncand,
                           const infx_cov_cand* cand, infx_cov_out* out, int32_t* feat_out);
 

@@ -81,8 +81,8 @@ struct infx_session {
     // the rank whose slice holds the query — this rank's own slice included; consumed by the next phase 0 (ph_plan, build_fused_inputs)
     // Own slice: parsed (plan, cq filled in by the collect).  A peer's: `rec` points at the query's record inside the retained blob (PlanSlab) and is parsed where
     // the plan is needed — on the planner threads of phase 0, straight into the batch's plan / coverage-query arrays — so the import itself costs a checksum.
-    struct OwnPlan { QueryPlan plan; infx_cov_query cq; };
-    struct PlanPre { uint64_t rawHash = 0; int32_t depth = 0, covErr = 0; bool hasCov = false; const uint8_t* rec = nullptr; uint32_t recLen = 0, covOff = 0; std::unique_ptr<OwnPlan> own; };
+    struct OwnPlan { QueryPlan plan; infx_cov_query cq; std::unique_ptr<infx_cov_query_long> cql; };
+    struct PlanPre { uint64_t rawHash = 0; int32_t depth = 0, covErr = 0; bool hasCov = false, longCov = false; const uint8_t* rec = nullptr; uint32_t recLen = 0, covOff = 0; std::unique_ptr<OwnPlan> own; };
     struct PlanSlab { std::vector<uint8_t> bytes; std::vector<PlanPre> pre; };
     std::vector<std::shared_ptr<PlanPre>> planPre;
     uint32_t planFromExchange = 0, planFromPeers = 0;      // last phase 0: queries planned from planPre / of them imported from another rank
@@ -195,15 +195,26 @@ uint64_t bytes_hash(const uint8_t* p, size_t n) {      // checksum of a blob sec
 struct BlobR { const uint8_t* p; const uint8_t* e; bool ok = true;
                template <class T> T get() { T v{}; if ((size_t)(e - p) < sizeof(T)) { ok = false; return v; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
                const uint8_t* take(size_t n) { if ((size_t)(e - p) < n) { ok = false; return nullptr; } const uint8_t* r = p; p += n; return r; } };
+// CoverageEngine.PrepareQuery into the fast record, or — beyond its envelope — into a long record (then `lq` is set and q is left zeroed: its `reserved` member
+// gets 1 + the record's index in the batch's long-query table when that is assembled).  INFX_EUNSUPPORTED: beyond the long envelope too.
+int32_t prepare_cov_any(const HostIndex& ix, uview st, infx_cov_query& q, std::unique_ptr<infx_cov_query_long>& lq) {
+    lq.reset();
+    int32_t rc = prepare_cov_query(ix, st, q);
+    if (rc != INFX_EUNSUPPORTED) return rc;
+    lq.reset(new infx_cov_query_long);
+    rc = prepare_cov_query_long(ix, st, *lq);
+    if (rc) lq.reset(); else std::memset(&q, 0, sizeof q);
+    return rc;
+}
 // One query's record of the plan exchange (layout: infx_session_prefetch_collect).  parse_plan_record fills the token-level plan and reports where the
 // coverage query sits; parse_cov_record rebuilds the infx_cov_query exactly as prepare_cov_query wrote it (its text is the plan's searchText).
 // Everything that reaches the device is range-checked.  nullptr = fine, else what is wrong.
-const char* parse_plan_record(const HostIndex& ix, const uint8_t* rec, uint32_t len, int depth, QueryPlan& P, bool& hasCov, int32_t& covErr, uint32_t& covOff) {
+const char* parse_plan_record(const HostIndex& ix, const uint8_t* rec, uint32_t len, int depth, QueryPlan& P, bool& hasCov, int32_t& covErr, uint32_t& covOff, bool& longCov) {
     BlobR R{rec, rec + len};
     auto str = [&](ustr& t) { const uint32_t l = R.get<uint32_t>(); const uint8_t* p = R.take((size_t)l * 2); if (!R.ok) return; t.resize(l); if (l) std::memcpy(&t[0], p, (size_t)l * 2); };
     P = QueryPlan(); P.depth = depth;
     R.get<uint64_t>(); const uint8_t fl = R.get<uint8_t>();
-    P.blank = (fl & 1) != 0; P.unsupported = (fl & 2) != 0; hasCov = (fl & 16) != 0; covErr = 0;
+    P.blank = (fl & 1) != 0; P.unsupported = (fl & 2) != 0; hasCov = (fl & 16) != 0; covErr = 0; longCov = (fl & 64) != 0;
     str(P.qtext); if (fl & 4) P.searchText = P.qtext; else str(P.searchText); if (fl & 8) P.tfidfQuery = P.searchText; else str(P.tfidfQuery);
     const uint16_t nraw = R.get<uint16_t>();
     if (!R.ok) return "record truncated";
@@ -219,22 +230,23 @@ const char* parse_plan_record(const HostIndex& ix, const uint8_t* rec, uint32_t 
     if (hasCov && (fl & 32)) { covErr = R.get<int32_t>(); if (!R.ok || covErr == 0) return "inconsistent coverage-query status"; }
     return nullptr;
 }
-const char* parse_cov_record(const ustr& searchText, const uint8_t* rec, uint32_t len, uint32_t covOff, infx_cov_query& C) {
+template <class QT, int MAXCHARS, int MAXTOK>
+const char* parse_cov_record_t(const ustr& searchText, const uint8_t* rec, uint32_t len, uint32_t covOff, QT& C) {
     if (covOff > len) return "record truncated";
     BlobR R{rec + covOff, rec + len};
     std::memset(&C, 0, sizeof C);
     const size_t tl = searchText.size();
-    if (tl > INFX_MAX_QUERY_CHARS) return "coverage query longer than the envelope";
+    if (tl > (size_t)MAXCHARS) return "coverage query longer than the envelope";
     std::memcpy(C.text, searchText.data(), tl * 2); C.text_len = (int32_t)tl;
     C.num_tokens = R.get<int32_t>();
-    if (!R.ok || C.num_tokens < 0 || C.num_tokens > INFX_MAX_QUERY_TOKENS) return "coverage query token count out of range";
+    if (!R.ok || C.num_tokens < 0 || C.num_tokens > MAXTOK) return "coverage query token count out of range";
     const size_t nt = (size_t)C.num_tokens; const uint8_t* p;
     if ((p = R.take(nt * 2))) std::memcpy(C.tok_off, p, nt * 2);
     if ((p = R.take(nt * 2))) std::memcpy(C.tok_len, p, nt * 2);
     if ((p = R.take(nt * 4))) std::memcpy(C.term_idf, p, nt * 4);
     if ((p = R.take(nt * 4))) std::memcpy(C.word_idf, p, nt * 4);
     C.has_word_idf = R.get<int32_t>(); C.num_fusion_tokens = R.get<int32_t>();
-    if (!R.ok || C.num_fusion_tokens < 0 || C.num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS) return "coverage query token count out of range";
+    if (!R.ok || C.num_fusion_tokens < 0 || C.num_fusion_tokens > 2 * MAXTOK) return "coverage query token count out of range";
     const size_t nf = (size_t)C.num_fusion_tokens;
     if ((p = R.take(nf * 2))) std::memcpy(C.ftok_off, p, nf * 2);
     if ((p = R.take(nf * 2))) std::memcpy(C.ftok_len, p, nf * 2);
@@ -244,6 +256,8 @@ const char* parse_cov_record(const ustr& searchText, const uint8_t* rec, uint32_
     for (size_t k = 0; k < nf; k++) if ((size_t)C.ftok_off[k] + C.ftok_len[k] > tl) return "coverage token outside its text";
     return nullptr;
 }
+const char* parse_cov_record(const ustr& st, const uint8_t* rec, uint32_t len, uint32_t covOff, infx_cov_query& C) { return parse_cov_record_t<infx_cov_query, INFX_MAX_QUERY_CHARS, INFX_MAX_QUERY_TOKENS>(st, rec, len, covOff, C); }
+const char* parse_cov_record_long(const ustr& st, const uint8_t* rec, uint32_t len, uint32_t covOff, infx_cov_query_long& C) { return parse_cov_record_t<infx_cov_query_long, INFX_LONGQ_CHARS, INFX_LONGQ_TOKENS>(st, rec, len, covOff, C); }
 }
 
 extern "C" {
@@ -498,7 +512,7 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
             infx_session::PlanPre* pre = havePre ? S->planPre[i].get() : nullptr;
             if (pre && pre->depth == depth && pre->rawHash == raw_hash((const uint16_t*)rp, rl)) {
                 // (the entry keeps its coverage query — parsed, or where it sits in the record — for build_fused_inputs)
-                if (pre->rec) { const char* why = parse_plan_record(ix, pre->rec, pre->recLen, depth, plans[i], pre->hasCov, pre->covErr, pre->covOff); if (why) badRec.store(why); }
+                if (pre->rec) { const char* why = parse_plan_record(ix, pre->rec, pre->recLen, depth, plans[i], pre->hasCov, pre->covErr, pre->covOff, pre->longCov); if (why) badRec.store(why); }
                 else plans[i] = std::move(pre->own->plan);
                 nPre++; if (S->planPeer[i]) nPeer++;
             } else {
@@ -924,7 +938,15 @@ static bool wm_on_device(const HostIndex& ix, const ustr& st) {
     });
     return same && words * (3 + 2 * ix.cfg.wmMaxLD1) <= INFX_MAX_WM_LISTS;
 }
-struct FusedIn { std::vector<infx_fused_query> fq; std::vector<infx_cov_query> cq; std::vector<infx_wm_list> lists; std::vector<int32_t> owned; };
+struct FusedIn { std::vector<infx_fused_query> fq; std::vector<infx_cov_query> cq; std::vector<infx_wm_list> lists; std::vector<int32_t> owned;
+                 std::vector<infx_cov_query_long> cql; };      // cql: the batch's long-query table (queries beyond the fast Stage-2 envelope; cq[i].reserved = 1 + index)
+// the long-query table goes to the stream in front of the Stage-2 call that consumes it (infx_search_fused / infx_shard_stage2)
+static int32_t stage_long_queries(infx_session* S, const FusedIn& F) {
+    if (F.cql.empty()) return INFX_OK;
+    int32_t rc = infx_stage2_long_queries(S->stream, (uint32_t)F.cql.size(), F.cql.data());
+    if (rc) g_eerr = infx_last_error();
+    return rc;
+}
 static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_results, int32_t enable_coverage, FusedIn& F) {
     Batch& B = *S->batch; const HostIndex& ix = e->ix; const int threads = e->threads; const uint32_t nq = B.nq;
     std::vector<QueryPlan>& plans = S->lastPlans;
@@ -933,6 +955,8 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
     fq.assign(nq, infx_fused_query{}); cq.assign(nq, infx_cov_query{});
     std::vector<std::vector<infx_wm_list>> qLists(nq); std::vector<std::vector<int32_t>> qOwned(nq);
     std::vector<int32_t> covErr(nq, 0);
+    std::vector<std::unique_ptr<infx_cov_query_long>> qLong(nq);      // queries beyond the fast envelope
+    F.cql.clear();
     bool devWm = e->devLookups && ix.cfg.wordMatcher;
     if (devWm) {      // ~2.5 looked-up words per query: estimated from the batch's text volume (one word per ~7 characters), 7 us of one core each
         size_t chars = 0; for (uint32_t i = 0; i < nq; i++) chars += plans[i].searchText.size();
@@ -955,10 +979,15 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
             const infx_session::PlanPre* pp = S->planPre.size() == nq ? S->planPre[i].get() : nullptr;      // (ph_plan dropped the entries that were not made for this batch)
             if (pp && pp->hasCov) {
                 covErr[i] = pp->covErr;
-                if (!covErr[i] && pp->rec) { if (const char* why = parse_cov_record(st, pp->rec, pp->recLen, pp->covOff, cq[i])) badRec.store(why); }
+                if (!covErr[i] && pp->longCov) {
+                    qLong[i].reset(new infx_cov_query_long);
+                    if (pp->rec) { if (const char* why = parse_cov_record_long(st, pp->rec, pp->recLen, pp->covOff, *qLong[i])) badRec.store(why); }
+                    else if (pp->own->cql) *qLong[i] = *pp->own->cql; else badRec.store("long coverage query missing");
+                }
+                else if (!covErr[i] && pp->rec) { if (const char* why = parse_cov_record(st, pp->rec, pp->recLen, pp->covOff, cq[i])) badRec.store(why); }
                 else if (!covErr[i]) cq[i] = pp->own->cq;
-            } else covErr[i] = prepare_cov_query(ix, st, cq[i]);
-            if (devWm && !covErr[i] && wm_on_device(ix, st)) { F.flags |= INFX_FQ_WMDEV; nDev++; continue; }      // k_wm resolves the words of cq[i] (lookup.hip.inc)
+            } else covErr[i] = prepare_cov_any(ix, st, cq[i], qLong[i]);
+            if (devWm && !covErr[i] && !qLong[i] && wm_on_device(ix, st)) { F.flags |= INFX_FQ_WMDEV; nDev++; continue; }      // k_wm resolves the words of cq[i] (lookup.hip.inc; fast-envelope queries)
             auto pre = S->wmPre.find(st);            // computed by a peer rank (sharded planning): same index, same text, same descriptors
             if (pre != S->wmPre.end()) { qLists[i] = pre->second.lists; qOwned[i] = pre->second.owned; }
             else wm_descriptors(ix, st, wm, qLists[i], qOwned[i]);
@@ -970,6 +999,7 @@ static int32_t build_fused_inputs(infx_engine* e, infx_session* S, int32_t max_r
     // flag bit 0) — it does not fail the other queries of the batch
     for (uint32_t i = 0; i < nq; i++) if (covErr[i]) { fq[i].flags = INFX_FQ_SKIP | INFX_FQ_UNSUPPORTED; qLists[i].clear(); qOwned[i].clear(); }
     e->wmOnDevice += nDev.load(); e->wmOnHost += nHost.load();
+    for (uint32_t i = 0; i < nq; i++) if (qLong[i] && !covErr[i]) { std::memset(&cq[i], 0, sizeof cq[i]); cq[i].reserved = 1 + (int32_t)F.cql.size(); F.cql.push_back(*qLong[i]); }
     lists.clear(); owned.clear();
     for (uint32_t i = 0; i < nq; i++) {
         fq[i].wm_off = (uint32_t)lists.size(); fq[i].wm_count = (uint32_t)qLists[i].size();
@@ -1023,6 +1053,7 @@ static int32_t search_batch_fused(infx_engine* e, infx_session* S, uint32_t nq, 
     auto& fq = FI.fq; auto& cq = FI.cq; auto& lists = FI.lists; auto& owned = FI.owned;
     B.t2 = now_ms();
     const bool dbg = e->cfg.want_features != 0;
+    rc = stage_long_queries(S, FI); if (rc) return rc;
     rc = infx_search_fused(S->stream, B.nd, B.dq.data(), (uint32_t)B.dterms.size(), B.dterms.data(), nq, fq.data(), cq.data(),
                            (uint32_t)lists.size(), lists.data(), (uint32_t)owned.size(), owned.data(), depth, max_results, dbg ? 1 : 0,
                            out_keys, out_scores, out_ties, out_counts, out_flags);
@@ -1161,7 +1192,7 @@ int64_t infx_session_prefetch_collect(infx_session* S, uint32_t nq, const uint16
             if (hostLookups) plan_tokens_expand(ix, e->fuzzy, P, false);
             if (!P.blank && !P.unsupported && ix.cfg.enableCoverage) {
                 if (hostLookups) wm_descriptors(ix, P.searchText, wm, qL[i], qO[i]);
-                R.hasCov = true; R.covErr = prepare_cov_query(ix, P.searchText, R.own->cq);
+                R.hasCov = true; R.covErr = prepare_cov_any(ix, P.searchText, R.own->cq, R.own->cql); R.longCov = (bool)R.own->cql;
             }
         }
     });
@@ -1187,7 +1218,8 @@ int64_t infx_session_prefetch_collect(infx_session* S, uint32_t nq, const uint16
     }
     // section 3, the plan exchange: u32 begin, end, nq; i32 depth; per query of the slice
     //   (table of n + 1 u32 record offsets first, so that an importer can find a record without parsing the ones before it)
-    //   u64 hash of the raw text; u8 flags (1 blank, 2 unsupported, 4 searchText == qtext, 8 tfidfQuery == searchText, 16 coverage query present, 32 .. outside the envelope)
+    //   u64 hash of the raw text; u8 flags (1 blank, 2 unsupported, 4 searchText == qtext, 8 tfidfQuery == searchText, 16 coverage query present, 32 .. outside the envelope,
+    //   64 .. in the long envelope: infx_cov_query_long)
     //   str qtext; [str searchText]; [str tfidfQuery]; u16 nraw { i32 id; [str text] }*       (str = u32 length + UTF-16 units; unknown words drop their expansion:
     //   the importer looks them up in ITS cache / expands them with the batch, as for its own queries)
     //   coverage query (its text is searchText): i32 status | i32 num_tokens, u16 tok_off[], u16 tok_len[], f32 term_idf[], f32 word_idf[], i32 has_word_idf,
@@ -1203,15 +1235,18 @@ int64_t infx_session_prefetch_collect(infx_session* S, uint32_t nq, const uint16
         const infx_session::PlanPre& R = *pres[i]; const QueryPlan& P = R.own->plan;
         const bool sameST = P.searchText == P.qtext, sameTQ = P.tfidfQuery == P.searchText;
         W.put<uint64_t>(R.rawHash);
-        W.put<uint8_t>((uint8_t)((P.blank ? 1 : 0) | (P.unsupported ? 2 : 0) | (sameST ? 4 : 0) | (sameTQ ? 8 : 0) | (R.hasCov ? 16 : 0) | (R.covErr ? 32 : 0)));
+        W.put<uint8_t>((uint8_t)((P.blank ? 1 : 0) | (P.unsupported ? 2 : 0) | (sameST ? 4 : 0) | (sameTQ ? 8 : 0) | (R.hasCov ? 16 : 0) | (R.covErr ? 32 : 0) | (R.longCov ? 64 : 0)));
         str(P.qtext); if (!sameST) str(P.searchText); if (!sameTQ) str(P.tfidfQuery);
         W.put<uint16_t>((uint16_t)P.rawTok.size());
         for (auto& r : P.rawTok) { W.put<int32_t>(r.id); if (r.id < 0) str(r.text); }
         if (R.hasCov && R.covErr) W.put<int32_t>(R.covErr);
         else if (R.hasCov) {
-            const infx_cov_query& C = R.own->cq; const size_t nt = (size_t)C.num_tokens, nf = (size_t)C.num_fusion_tokens;
-            W.put<int32_t>(C.num_tokens); W.bytes(C.tok_off, nt * 2); W.bytes(C.tok_len, nt * 2); W.bytes(C.term_idf, nt * 4); W.bytes(C.word_idf, nt * 4);
-            W.put<int32_t>(C.has_word_idf); W.put<int32_t>(C.num_fusion_tokens); W.bytes(C.ftok_off, nf * 2); W.bytes(C.ftok_len, nf * 2); W.put<int32_t>(C.lcs_tolerance);
+            auto putcov = [&](const auto& C) {
+                const size_t nt = (size_t)C.num_tokens, nf = (size_t)C.num_fusion_tokens;
+                W.put<int32_t>(C.num_tokens); W.bytes(C.tok_off, nt * 2); W.bytes(C.tok_len, nt * 2); W.bytes(C.term_idf, nt * 4); W.bytes(C.word_idf, nt * 4);
+                W.put<int32_t>(C.has_word_idf); W.put<int32_t>(C.num_fusion_tokens); W.bytes(C.ftok_off, nf * 2); W.bytes(C.ftok_len, nf * 2); W.put<int32_t>(C.lcs_tolerance);
+            };
+            if (R.longCov) putcov(*R.own->cql); else putcov(R.own->cq);
         }
     }
     tabput(n);
@@ -1306,14 +1341,15 @@ int32_t infx_session_plan_digest(infx_session* S, uint32_t nq, const uint16_t* q
         if (R && R->depth == depth && R->rawHash == raw_hash((const uint16_t*)rp, rl)) {
             used++;
             if (R->rec) {      // a peer's record: parsed here as phase 0 would
-                const char* why = parse_plan_record(ix, R->rec, R->recLen, depth, local.own->plan, local.hasCov, local.covErr, local.covOff);
-                if (!why && local.hasCov && !local.covErr) why = parse_cov_record(local.own->plan.searchText, R->rec, R->recLen, local.covOff, local.own->cq);
+                const char* why = parse_plan_record(ix, R->rec, R->recLen, depth, local.own->plan, local.hasCov, local.covErr, local.covOff, local.longCov);
+                if (!why && local.hasCov && !local.covErr && local.longCov) { local.own->cql.reset(new infx_cov_query_long); why = parse_cov_record_long(local.own->plan.searchText, R->rec, R->recLen, local.covOff, *local.own->cql); }
+                else if (!why && local.hasCov && !local.covErr) why = parse_cov_record(local.own->plan.searchText, R->rec, R->recLen, local.covOff, local.own->cq);
                 if (why) return efail(INFX_EINVAL, std::string("exchanged plan record: ") + why);
                 R = &local;
             }
         } else {
             plan_tokens_text(ix, uview(rp, rl), depth, local.own->plan);
-            if (!local.own->plan.blank && !local.own->plan.unsupported && ix.cfg.enableCoverage) { local.hasCov = true; local.covErr = prepare_cov_query(ix, local.own->plan.searchText, local.own->cq); }
+            if (!local.own->plan.blank && !local.own->plan.unsupported && ix.cfg.enableCoverage) { local.hasCov = true; local.covErr = prepare_cov_any(ix, local.own->plan.searchText, local.own->cq, local.own->cql); local.longCov = (bool)local.own->cql; }
             R = &local;
         }
         uint64_t h = 1469598103934665603ull;
@@ -1321,7 +1357,7 @@ int32_t infx_session_plan_digest(infx_session* S, uint32_t nq, const uint16_t* q
         const QueryPlan& P = R->own->plan; const uint8_t fl = (uint8_t)((P.blank ? 1 : 0) | (P.unsupported ? 2 : 0) | (R->hasCov ? 4 : 0)); const int32_t d = P.depth;
         mix(&fl, 1); mix(&d, 4); mix(P.qtext.data(), P.qtext.size() * 2); mix(P.searchText.data(), P.searchText.size() * 2); mix(P.tfidfQuery.data(), P.tfidfQuery.size() * 2);
         for (auto& r : P.rawTok) { mix(&r.id, 4); mix(r.text.data(), r.text.size() * 2); }
-        if (R->hasCov) { mix(&R->covErr, 4); if (!R->covErr) mix(&R->own->cq, sizeof R->own->cq); }
+        if (R->hasCov) { mix(&R->covErr, 4); const uint8_t lg = R->longCov ? 1 : 0; mix(&lg, 1); if (!R->covErr && R->longCov) mix(R->own->cql.get(), sizeof(infx_cov_query_long)); else if (!R->covErr) mix(&R->own->cq, sizeof R->own->cq); }
         out[i] = h;
     }
     if (from_exchange) *from_exchange = used;
@@ -1604,6 +1640,7 @@ int32_t infx_session_phase3(infx_session* S, int32_t W, const infx_hit* all_hits
     B.t3 = now_ms();
     S->lastOuts.assign((size_t)B.nq * 2 * B.depth, infx_cov_out{});
     if (B.nq) {
+        rc = stage_long_queries(S, FI); if (rc) return rc;
         rc = infx_shard_stage2(S->stream, W, B.nd, all_hits, all_counts, B.nq, FI.fq.data(), FI.cq.data(), (uint32_t)FI.lists.size(), FI.lists.data(),
                                (uint32_t)FI.owned.size(), FI.owned.data(), B.depth, max_results, 0, S->lastOuts.data());
         if (rc) { g_eerr = infx_last_error(); return rc; }
@@ -1639,6 +1676,7 @@ int32_t infx_session_phase3x(infx_session* S, int32_t W, const void* all_hits, c
     FusedIn& FI = *FIp;
     B.t3 = now_ms();
     if (B.nq) {
+        rc = stage_long_queries(S, FI); if (rc) return rc;
         rc = infx_shard_stage2(S->stream, W, B.nd, (const infx_hit*)all_hits, (const uint32_t*)all_counts, B.nq, FI.fq.data(), FI.cq.data(), (uint32_t)FI.lists.size(), FI.lists.data(),
                                (uint32_t)FI.owned.size(), FI.owned.data(), B.depth, max_results, 0, (infx_cov_out*)outs);
         if (rc) { g_eerr = infx_last_error(); return rc; }
@@ -1791,8 +1829,8 @@ int32_t infx_engine_host_plan_profile(infx_engine* e, uint32_t nq, const uint16_
         const int32_t rc = infx_session_prefetch_import(e->def, blob.data(), (int64_t)blob.size());
         t8 = std::chrono::steady_clock::now();
         if (!rc) {      // [7]: what phase 0 then pays per imported query instead of [5] + [4]: parsing the record into the plan and the coverage query
-            QueryPlan tmp; infx_cov_query tc; bool hc; int32_t ce; uint32_t co;
-            for (auto& pp : e->def->planPre) if (pp && pp->rec && !parse_plan_record(ix, pp->rec, pp->recLen, depth, tmp, hc, ce, co) && hc && !ce) sink += parse_cov_record(tmp.searchText, pp->rec, pp->recLen, co, tc) ? 1 : 0;
+            QueryPlan tmp; infx_cov_query tc; bool hc, lg; int32_t ce; uint32_t co;
+            for (auto& pp : e->def->planPre) if (pp && pp->rec && !parse_plan_record(ix, pp->rec, pp->recLen, depth, tmp, hc, ce, co, lg) && hc && !ce && !lg) sink += parse_cov_record(tmp.searchText, pp->rec, pp->recLen, co, tc) ? 1 : 0;
         }
         t9 = std::chrono::steady_clock::now();
         e->def->planPre.clear(); e->def->planPeer.clear(); e->def->wmPre.clear();
@@ -1898,6 +1936,14 @@ int32_t infx_engine_prepare_cov_query(infx_engine* e, const uint16_t* q, int32_t
     return prepare_cov_query(e->ix, P.searchText, *out);
 }
 int32_t infx_sizeof_cov_query(void) { return (int32_t)sizeof(infx_cov_query); }
+// the same for a query beyond the fast envelope: the record of the long-query table (infx_stage2_long_queries)
+int32_t infx_engine_prepare_cov_query_long(infx_engine* e, const uint16_t* q, int32_t len, infx_cov_query_long* out) {
+    if (!e || !out || (len && !q)) return efail(INFX_EINVAL, "null argument");
+    QueryPlan P; plan_tokens_text(e->ix, uview((const u16*)q, (size_t)len), 500, P);
+    if (P.blank || P.unsupported) return efail(INFX_EINVAL, "blank or unsupported query");
+    return prepare_cov_query_long(e->ix, P.searchText, *out);
+}
+int32_t infx_sizeof_cov_query_long(void) { return (int32_t)sizeof(infx_cov_query_long); }
 int32_t infx_engine_effective_cpus(void) { return effective_cpus(); }
 // parity tooling: switch the introspection downloads (Stage-1 rows, Stage-2 candidates / features of the last batch) on or off at run time
 int32_t infx_engine_set_introspection(infx_engine* e, int32_t on) { if (!e) return INFX_EINVAL; e->cfg.want_features = on ? 1 : 0; return INFX_OK; }

@@ -538,9 +538,11 @@ inline void wm_first_unique(const WmResult& R, const std::vector<int32_t>& exclu
 }
 
 // ---- CoverageEngine.PrepareQuery -------------------------------------------------------------------------------------------
-inline int32_t prepare_cov_query(const HostIndex& ix, uview query, infx_cov_query& C) {
+// QT = infx_cov_query (the fast envelope: INFX_MAX_QUERY_CHARS / INFX_MAX_QUERY_TOKENS) or infx_cov_query_long (INFX_LONGQ_CHARS / INFX_LONGQ_TOKENS); same members.
+template <class QT, int MAXCHARS, int MAXTOK>
+inline int32_t prepare_cov_query_t(const HostIndex& ix, uview query, QT& C) {
     std::memset(&C, 0, sizeof C);
-    if ((int)query.size() > INFX_MAX_QUERY_CHARS) return INFX_EUNSUPPORTED;
+    if ((int)query.size() > MAXCHARS) return INFX_EUNSUPPORTED;
     std::memcpy(C.text, query.data(), query.size() * 2); C.text_len = (int)query.size();
     struct Tk { int off, len; };
     std::vector<Tk> raw, uq, fus;
@@ -550,7 +552,7 @@ inline int32_t prepare_cov_query(const HostIndex& ix, uview query, infx_cov_quer
         for (auto& u : uq) if (ic_equal(query.substr(u.off, u.len), query.substr(t.off, t.len))) { dup = true; break; }      // CoverageTokenizer.cs:50-57: OrdinalIgnoreCase
         if (!dup) uq.push_back(t);
     }
-    if ((int)uq.size() > INFX_MAX_QUERY_TOKENS || (int)fus.size() > 2 * INFX_MAX_QUERY_TOKENS) return INFX_EUNSUPPORTED;
+    if ((int)uq.size() > MAXTOK || (int)fus.size() > 2 * MAXTOK) return INFX_EUNSUPPORTED;
     C.num_tokens = (int)uq.size();
     const int n = ix.cfg.ngram;
     for (int i = 0; i < (int)uq.size(); i++) {
@@ -569,5 +571,8 @@ inline int32_t prepare_cov_query(const HostIndex& ix, uview query, infx_cov_quer
     C.lcs_tolerance = (int)query.size() >= 5 ? (int)((double)query.size() * 0.2) : 0;
     return INFX_OK;
 }
+inline int32_t prepare_cov_query(const HostIndex& ix, uview query, infx_cov_query& C) { return prepare_cov_query_t<infx_cov_query, INFX_MAX_QUERY_CHARS, INFX_MAX_QUERY_TOKENS>(ix, query, C); }
+// a query beyond the fast envelope (prepare_cov_query returned INFX_EUNSUPPORTED): the long record (include/infidex_hip.h); INFX_EUNSUPPORTED again = beyond that too
+inline int32_t prepare_cov_query_long(const HostIndex& ix, uview query, infx_cov_query_long& C) { return prepare_cov_query_t<infx_cov_query_long, INFX_LONGQ_CHARS, INFX_LONGQ_TOKENS>(ix, query, C); }
 
 } // namespace infx

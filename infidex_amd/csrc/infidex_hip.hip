@@ -287,6 +287,7 @@ struct infx_stream {
     void* dCounts = nullptr; size_t capCounts = 0;
     void* dDense = nullptr; size_t capDense = 0; bool useSr = false;      // k_accumulate_sr -> k_accumulate hand-over flags, one byte per (query, container)
     void* dCovQ = nullptr; size_t capCovQ = 0;
+    void* dCovQL = nullptr; size_t capCovQL = 0; uint32_t nLongQ = 0;      // infx_stage2_long_queries: the long-query table of the next Stage-2 call
     void* dCovC = nullptr; size_t capCovC = 0;
     void* dCovO = nullptr; size_t capCovO = 0;
     void* dCovF = nullptr; size_t capCovF = 0;
@@ -356,10 +357,17 @@ static int s2_waves() { static const int w = [] { const char* e = getenv("INFX_S
 // LDS pool of the fast launch: UTF-16 units of document text per 64-candidate workgroup (INFX_S2_POOL overrides; 0 = texts stay in global memory)
 static int s2_pool() { static const int w = [] { const char* e = getenv("INFX_S2_POOL"); int v = e ? atoi(e) : S2_POOL_CHARS; return (v < 0 || v > 32768) ? S2_POOL_CHARS : v; }(); return w; }
 #define S2_GRID(lds) (ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, (lds), s->st
-#define S2_LAUNCH_FAST(...) do { const int pool_ = s2_pool(); switch (s2_waves()) { case 2: k_stage2<S2_FASTD, 2><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; case 6: k_stage2<S2_FASTD, 6><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; \
-                                                     case 8: k_stage2<S2_FASTD, 8><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; default: k_stage2<S2_FASTD, 4><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, pool_); break; } } while (0)
+#define S2_FAST_TAIL pool_, (uint16_t*)nullptr, (uint32_t*)nullptr, 0u, (const infx_cov_query_long*)nullptr, s->nLongQ      /* the first launch tells long-query rows apart (and checks their table index) */
+#define S2_LAUNCH_FAST(...) do { const int pool_ = s2_pool(); switch (s2_waves()) { case 2: k_stage2<S2_FASTD, 2><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; case 6: k_stage2<S2_FASTD, 6><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; \
+                                                     case 8: k_stage2<S2_FASTD, 8><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; default: k_stage2<S2_FASTD, 4><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; } } while (0)
 #define S2_LAUNCH_SLOW(...) k_stage2<S2_MAXD, 4><<<S2_GRID(0)>>>(__VA_ARGS__, 0)
 #define S2_LAUNCH_HUGE(...) k_stage2<S2_HUGE_TOKENS, 1, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16)
+// rows of long queries (marked by the first launch): documents up to S2_MAXD words, then the rest through the global-workspace pass; nothing is launched for a batch without long queries.
+// The table is consumed: the next Stage-2 call starts without one.
+#define S2_LAUNCH_LONGQ(...) do { if (s->nLongQ) { \
+    k_stage2<S2_MAXD, 2, false, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)nullptr, (uint32_t*)nullptr, 0u, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
+    k_stage2<S2_HUGE_TOKENS, 1, true, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
+    s->nLongQ = 0; } } while (0)
 static int32_t s2_huge_ready(infx_stream* s);
 
 // ---- host <-> device transfers through pinned staging -------------------------------------------------------------------
@@ -1331,6 +1339,24 @@ int32_t infx_stage1_batch(infx_stream* s, uint32_t nq, const infx_query* q, uint
     return infx_stage1_select(s, nq, counts.data(), out, out_count);
 }
 
+int32_t infx_stage2_long_queries(infx_stream* s, uint32_t n, const infx_cov_query_long* q) {
+    if (!s || (n && !q)) return fail(INFX_EINVAL, "null argument%s");
+    s->nLongQ = 0;
+    if (!n) return INFX_OK;
+    infx_index* ix = s->ix;
+    HIPCHK(hipSetDevice(ix->cfg.device));
+    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    for (uint32_t i = 0; i < n; i++)
+        if (q[i].num_tokens < 0 || q[i].num_tokens > INFX_LONGQ_TOKENS || q[i].text_len < 0 || q[i].text_len > INFX_LONGQ_CHARS || q[i].num_fusion_tokens < 0 || q[i].num_fusion_tokens > 2 * INFX_LONGQ_TOKENS)
+            return fail(INFX_EUNSUPPORTED, "query exceeds the long Stage-2 envelope%s");
+    GROW(s->dCovQL, s->capCovQL, (size_t)n * sizeof(infx_cov_query_long));
+    UP(s->dCovQL, q, (size_t)n * sizeof(infx_cov_query_long));
+    k_fold_ic_longq<<<n, WAVE, 0, s->st>>>((infx_cov_query_long*)s->dCovQL, n);
+    HIPCHK(hipGetLastError());
+    s->nLongQ = n;
+    return INFX_OK;
+}
+
 int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, uint32_t ncand, const infx_cov_cand* cand,
                           infx_cov_out* out, int32_t* feat_out) {
     if (!s || (ncand && (!q || !cand || !out))) return fail(INFX_EINVAL, "null argument%s");
@@ -1339,9 +1365,11 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     if (!ix->haveDocs || !ix->d.text) return fail(INFX_EINVAL, "document text not uploaded%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
-    for (uint32_t i = 0; i < nq; i++)
+    for (uint32_t i = 0; i < nq; i++) {
+        if (q[i].reserved != 0) { if (q[i].reserved < 0 || (uint32_t)q[i].reserved > s->nLongQ) return fail(INFX_EINVAL, "query refers to a missing long-query record (infx_stage2_long_queries)%s"); continue; }
         if (q[i].num_tokens > INFX_MAX_QUERY_TOKENS || q[i].text_len > INFX_MAX_QUERY_CHARS || q[i].num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS)
-            return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope%s");
+            return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope (hand it over as a long query: infx_stage2_long_queries)%s");
+    }
     GROW(s->dCovQ, s->capCovQ, (size_t)nq * sizeof(infx_cov_query));
     GROW(s->dCovC, s->capCovC, (size_t)ncand * sizeof(infx_cov_cand));
     GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
@@ -1356,6 +1384,8 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
                                                                                  (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 1, nullptr);
     { int32_t rc_ = s2_huge_ready(s); if (rc_) return rc_; }
     S2_LAUNCH_HUGE(ix->d, (const infx_cov_query*)s->dCovQ, nq,
+                                                                                 (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 1, nullptr);
+    S2_LAUNCH_LONGQ(ix->d, (const infx_cov_query*)s->dCovQ, nq,
                                                                                  (const infx_cov_cand*)s->dCovC, ncand, (infx_cov_out*)s->dCovO, feat_out ? (int32_t*)s->dCovF : nullptr, 0, 1, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
@@ -1490,7 +1520,7 @@ static uint32_t wm_words(const infx_cov_query& c) {      // words k_wm looks up:
     return n;
 }
 static int32_t fused_check_queries(infx_index* ix, uint32_t nd, uint32_t nq, const infx_fused_query* fq, const infx_cov_query* cq,
-                                   uint32_t nlists, const infx_wm_list* lists, uint32_t owned_n, int32_t depth, int32_t max_results) {
+                                   uint32_t nlists, const infx_wm_list* lists, uint32_t owned_n, int32_t depth, int32_t max_results, uint32_t nLong) {
     if (nd > nq || max_results < 1 || depth < 1 || depth > ix->cfg.max_depth) return fail(INFX_EINVAL, "bad batch shape%s");
     bool anyWm = false;
     for (uint32_t i = 0; i < nq; i++) {
@@ -1503,9 +1533,12 @@ static int32_t fused_check_queries(infx_index* ix, uint32_t nd, uint32_t nq, con
             if ((fq[i].flags & INFX_FQ_COV) && !(fq[i].flags & INFX_FQ_SKIP) && wm_words(cq[i]) * (uint32_t)(3 + 2 * ix->lk->maxLd1) > INFX_MAX_WM_LISTS)
                 return fail(INFX_ECAPACITY, "too many words for the device WordMatcher lookup (hand the lists over instead)%s");
         }
-        if ((fq[i].flags & INFX_FQ_COV) && !(fq[i].flags & INFX_FQ_SKIP) &&
+        if ((fq[i].flags & INFX_FQ_COV) && !(fq[i].flags & INFX_FQ_SKIP) && cq[i].reserved != 0) {
+            if (cq[i].reserved < 0 || (uint32_t)cq[i].reserved > nLong) return fail(INFX_EINVAL, "query refers to a missing long-query record (infx_stage2_long_queries)%s");
+            if (fq[i].flags & INFX_FQ_WMDEV) return fail(INFX_EINVAL, "the device WordMatcher lookup reads the words of a fast-envelope query: hand the lists of a long query over%s");
+        } else if ((fq[i].flags & INFX_FQ_COV) && !(fq[i].flags & INFX_FQ_SKIP) &&
             (cq[i].num_tokens > INFX_MAX_QUERY_TOKENS || cq[i].text_len > INFX_MAX_QUERY_CHARS || cq[i].num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS))
-            return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope%s");
+            return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope (hand it over as a long query: infx_stage2_long_queries)%s");
     }
     for (uint32_t l = 0; l < nlists; l++) {
         const infx_wm_list& L = lists[l];
@@ -1605,6 +1638,8 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
                                                                                  (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 1, (const int32_t*)s->dFPairs);
     { int32_t rc_ = s2_huge_ready(s); if (rc_) return rc_; }
     S2_LAUNCH_HUGE(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
+                                                                                 (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 1, (const int32_t*)s->dFPairs);
+    S2_LAUNCH_LONGQ(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
                                                                                  (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 1, (const int32_t*)s->dFPairs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evC1, s->st));
@@ -1717,7 +1752,7 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
     if (!ix->havePostings || !ix->haveDocs || !ix->d.text) return fail(INFX_EINVAL, "index not uploaded%s");
     if (ix->nranks > 1 || ix->d.docBase != 0) return fail(INFX_EINVAL, "infx_search_fused needs an unsharded index (sharded engines use infx_shard_*)%s");
     if (nq == 0) return INFX_OK;
-    { int32_t rc_ = fused_check_queries(ix, nd, nq, fq, cq, nlists, lists, owned_n, depth, max_results); if (rc_) return rc_; }
+    { int32_t rc_ = fused_check_queries(ix, nd, nq, fq, cq, nlists, lists, owned_n, depth, max_results, s->nLongQ); if (rc_) return rc_; }
     for (uint32_t i = 0; i < nd; i++) if (q[i].depth != depth) return fail(INFX_EINVAL, "all queries of a fused batch share one depth%s");
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
@@ -1782,7 +1817,7 @@ int32_t infx_shard_stage2(infx_stream* s, int32_t nshards, uint32_t nd, const in
     infx_index* ix = s->ix;
     if (!ix->haveDocs || !ix->d.text || !ix->d.docKeyAll) return fail(INFX_EINVAL, "index not uploaded%s");
     if (nq == 0) return INFX_OK;
-    { int32_t rc_ = fused_check_queries(ix, nd, nq, fq, cq, nlists, lists, owned_n, depth, max_results); if (rc_) return rc_; }
+    { int32_t rc_ = fused_check_queries(ix, nd, nq, fq, cq, nlists, lists, owned_n, depth, max_results, s->nLongQ); if (rc_) return rc_; }
     HIPCHK(hipSetDevice(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     const size_t nh = (size_t)nshards * std::max<size_t>(1, nd) * depth;

@@ -197,6 +197,8 @@ def test_sharded_equals_the_oracle():
     sess = [ShardSession(e) for e in engs]
     qa, qo = s.queries(200, qseed=21, fuzz=0.3)
     qs = Synth.texts(qa, qo) + ["qu", "zzzzqq", "the"]
+    qs.append(" ".join(dict.fromkeys(w for t in qs[:40] for w in t.split())))      # > 32 distinct words: the long-query table travels through infx_shard_stage2 too
+    assert len(qs[-1].split()) > 32
     a2, o2 = pack_texts(qs)
     host = simulate_shards(sess, a2, o2, 10)
     dev = simulate_shards_dev(sess, a2, o2, 10)
@@ -254,7 +256,7 @@ np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c)
 def test_long_documents_take_the_retry_launches():
     """Documents with more than 32 words are re-scored by the second k_stage2 launch (192-word tables in scratch), documents beyond 192 words by the third
     (tables in a global workspace: any text the reference accepts, Api/DocumentFields.cs:140): rows, features and scores must match the oracle whatever
-    launch scored them.  A query beyond INFX_MAX_QUERY_CHARS is answered as unsupported without failing its batch."""
+    launch scored them.  A query beyond INFX_LONGQ_CHARS is answered as unsupported without failing its batch."""
     import random
     rng = random.Random(3)
     vocab = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet", "kilo", "lima", "mike",
@@ -278,8 +280,51 @@ def test_long_documents_take_the_retry_launches():
     assert 400 < len(long_q) <= 512
     st = compare_batch(e, o, [long_q, "alpha bravo"], 10)
     assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, st
-    r = e.search_batch(["alpha bravo", "x" * 600], 5)
-    assert r[1].unsupported and not r[1].records and not r[0].unsupported and r[0].records       # beyond INFX_MAX_QUERY_CHARS: unsupported, the batch goes on
+    r = e.search_batch(["alpha bravo", "x" * 2100], 5)
+    assert r[1].unsupported and not r[1].records and not r[0].unsupported and r[0].records       # beyond INFX_LONGQ_CHARS: unsupported, the batch goes on
+
+
+def test_long_queries_take_the_long_query_launches():
+    """The reference puts no limit on the query (CoverageEngine.cs:68).  Queries beyond 32 distinct words / 512 characters are scored by k_stage2's long-query
+    launches (128-word tables, four mask words; documents beyond 192 words through the global-workspace pass): rows, features and scores must match the
+    oracle for 40-, 100- and 128-word queries and a 600-character one, mixed with ordinary queries in one batch; only a query beyond 128 distinct words or
+    2048 characters is answered as unsupported."""
+    import random
+    rng = random.Random(17)
+    vocab = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet", "kilo", "lima", "mike",
+             "november", "oscar", "papa", "quebec", "romeo", "sierra", "tango", "uniform", "victor", "whiskey", "xray", "yankee", "zulu"]
+    word = lambda: rng.choice(vocab) + (str(rng.randrange(40)) if rng.random() < 0.5 else "")
+    docs = []
+    for i in range(400):
+        n = rng.choice([5, 12, 31, 33, 40, 64, 100, 150, 190, 193, 260, 700])
+        docs.append((i, " ".join(word() for _ in range(n))))
+    docs.append((400, " ".join(vocab[i % 26] + str(i) for i in range(2500))))                       # 2 500 distinct words: the global-workspace pass
+    long1 = " ".join(vocab[i % 26] + str(i) for i in range(100))                                       # 100 distinct words, all of document 400
+    docs.append((401, long1))                                                                          # ... and a document that IS the query
+    docs.append((402, " ".join(vocab[i % 26] + str(i) for i in range(0, 200, 2))))
+    e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+    o = O.OracleEngine.create_default(); o.index(docs)
+    q40 = " ".join(vocab[i % 26] + str(i % 40) for i in range(40))
+    q40typo = " ".join((vocab[i % 26][:-1] + "x" if i % 7 == 3 else vocab[i % 26]) + str(i % 40) for i in range(40))      # some words one edit away
+    q128 = " ".join(vocab[i % 26] + str(i) for i in range(128))
+    q600 = " ".join(["alphabravocharliedeltaechofoxtrotgolfhotelindiajulietkilolimamike" + str(i) for i in range(9)]) + " alpha bravo"
+    q33 = " ".join(vocab[i % 26] + str(i) for i in range(33))                                          # one word beyond the fast envelope
+    assert len(q600) > 512 and len(set(q128.split())) == 128 and len(q128) <= 2048
+    qs = ["alpha bravo", q40, "charlie delta echo", long1, q40typo, q128, q600, "zulu2495 alpha2496", q33, long1 + " " + long1.split()[0]]
+    res = e.search_batch(qs, 10)
+    assert not any(r.unsupported or r.skipped_candidates for r in res), [(r.unsupported, r.skipped_candidates) for r in res]
+    assert res[3].records[0].document_id == 401                                                        # the document that is the 100-word query comes first
+    st = compare_batch(e, o, qs, 10)
+    assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0 and st["order_unclassified"] == 0, st
+    # the same long queries alone and in another order: batching is transparent for them too
+    st = compare_batch(e, o, [q128, q40], 10)
+    assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0, st
+    # beyond the long envelope: unsupported, the rest of the batch is answered
+    q129 = q128 + " zulu9999"
+    r = e.search_batch([q129, "alpha bravo", "x" * 2049, q40], 5)
+    assert r[0].unsupported and not r[0].records and r[2].unsupported and not r[2].records
+    assert not r[1].unsupported and r[1].records and not r[3].unsupported and r[3].records
+    assert [x.document_id for x in r[3].records] == o.search(q40, 5)["keys"]
 
 
 def test_long_tokens_have_no_length_limit():

@@ -376,3 +376,51 @@ def test_characters_outside_the_bmp_index_and_plan_like_the_oracle():
         assert np.array_equal(prod.wordmatcher(q), orc.wordmatcher(_norm(q, lower=True))), q
         planned += 1
     assert planned >= 10
+
+
+def test_query_envelopes_of_the_coverage_context():
+    """CoverageEngine.PrepareQuery has no limit on the query (CoverageEngine.cs:68 rents query.Length / 2 + 1 token slots).  Here a query inside
+    INFX_MAX_QUERY_TOKENS / INFX_MAX_QUERY_CHARS (32 distinct words, 512 characters) gets the fast record, one inside INFX_LONGQ_TOKENS / INFX_LONGQ_CHARS
+    (128 / 2048) the long record with the same members, and only a query beyond that is answered as unsupported."""
+    import ctypes as C
+    from infidex_amd import SearchEngine
+    from infidex_amd.engine import _p, _u16, Document
+    e = SearchEngine.create_default(device=-1)
+    e.index_documents([Document(i, "alpha bravo charlie w%dq delta" % i) for i in range(50)])
+    L = e.L
+    szs, szl = L.infx_sizeof_cov_query(), L.infx_sizeof_cov_query_long()
+    assert szl > szs
+
+    def short(q):
+        a = _u16(q); buf = (C.c_uint8 * szs)()
+        return L.infx_engine_prepare_cov_query(e.h, _p(a, C.c_uint16), len(a), buf), bytes(buf)
+
+    def long_(q):
+        a = _u16(q); buf = (C.c_uint8 * szl)()
+        return L.infx_engine_prepare_cov_query_long(e.h, _p(a, C.c_uint16), len(a), buf), bytes(buf)
+
+    def fields(raw, chars, toks):      # text_len, num_tokens, tok_off[:n], tok_len[:n], num_fusion_tokens of either record layout
+        o = 2 * chars
+        tl, nt = np.frombuffer(raw, np.int32, 2, o)
+        off = np.frombuffer(raw, np.uint16, toks, o + 8)[:nt]; ln = np.frombuffer(raw, np.uint16, toks, o + 8 + 2 * toks)[:nt]
+        idf = np.frombuffer(raw, np.float32, toks, o + 8 + 4 * toks)[:nt]
+        nf = int(np.frombuffer(raw, np.int32, 2, o + 8 + 12 * toks)[1])
+        return int(tl), int(nt), off.tolist(), ln.tolist(), idf.tolist(), nf
+
+    q32 = " ".join("w%dq" % i for i in range(32)); q33 = q32 + " w32q"; q128 = " ".join("w%dq" % i for i in range(128)); q129 = q128 + " w128q"
+    rc, raw = short(q32); assert rc == 0 and fields(raw, 512, 32)[1] == 32
+    assert short(q33)[0] == 5 and short("x" * 513)[0] == 5                      # INFX_EUNSUPPORTED: beyond the fast envelope
+    rc, raw = long_(q33); f = fields(raw, 2048, 128)
+    assert rc == 0 and f[0] == len(q33) and f[1] == 33 and f[5] == 33
+    words = q33.split(" "); pos = [q33.index(w + " ") if i < 32 else len(q33) - len(w) for i, w in enumerate(words)]
+    assert f[2] == pos and f[3] == [len(w) for w in words]
+    # the same query prepared both ways carries the same token tables and idf values
+    rs, raws = short(q32); rl, rawl = long_(q32)
+    assert rs == 0 and rl == 0 and fields(raws, 512, 32) == fields(rawl, 2048, 128)
+    rc, raw = long_(q128); assert rc == 0 and fields(raw, 2048, 128)[1] == 128
+    assert long_(q129)[0] == 5 and long_("x" * 2049)[0] == 5
+    rc, raw = long_("x" * 2048); assert rc == 0 and fields(raw, 2048, 128)[:2] == (2048, 1)
+    # repeated words count once (CoverageTokenizer.DeduplicateQueryTokens), unfiltered tokens all count
+    rc, raw = long_(" ".join(["alpha", "bravo"] * 100)); f = fields(raw, 2048, 128)
+    assert rc == 0 and f[1] == 2 and f[5] == 200
+    assert long_(" ".join(["alpha", "bravo"] * 129))[0] == 5                      # 258 unfiltered tokens > 2 * INFX_LONGQ_TOKENS

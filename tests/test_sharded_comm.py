@@ -81,7 +81,8 @@ def _prefetch_worker(rank, world, port, q):
     e = SearchEngine.create_default(device=-1); e.index_flat(None, arena, offs, s.field_weights)
     from infidex_amd.engine import pack_texts
     # blank, short ("unsupported"), beyond the Stage-2 envelope (too long / too many distinct words), outside the BMP: every kind of plan record crosses
-    extras = ["", "   ", "qu", "x" * 600, " ".join("w%dq" % i for i in range(40)), "caf\u00e9 \U0001F50D na\u00efve", "ab cd ef"]
+    # (600 characters / 40 distinct words: the long coverage record; 2100 characters / 140 words: beyond that, an error status crosses)
+    extras = ["", "   ", "qu", "x" * 600, " ".join("w%dq" % i for i in range(40)), "y" * 2100, " ".join("v%dq" % i for i in range(140)), "caf\u00e9 \U0001F50D na\u00efve", "ab cd ef"]
     qa, qo = s.queries(200, qseed=5, fuzz=0.6)
     qa, qo = pack_texts(Synth.texts(qa, qo) + extras)
     nq = len(qo) - 1
