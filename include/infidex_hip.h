@@ -218,7 +218,8 @@ typedef struct infx_cov_cand {
     uint32_t query;        /* index into the batch's infx_cov_query[] */
     int32_t  doc;          /* shard-local internal id */
     float    base_score;   /* normBm25 = s / s_top1, or 0 for WordMatcher candidates (SearchPipeline.cs:380-414) */
-    int32_t  want_lcs;     /* 1 for docIndex < 2 (quirk Q7, SearchPipeline.cs:492-503) */
+    int32_t  want_lcs;     /* 1 for docIndex < 2 (quirk Q7, SearchPipeline.cs:492-503); 2: the same document's SECOND evaluation (its Stage-1 row after its WordMatcher
+                              overlap row): the reference reads the LCS back from a byte span there, so a value above 255 comes back as 255 (quirk Q18, :494-503) */
 } infx_cov_cand;
 
 typedef struct infx_cov_out {

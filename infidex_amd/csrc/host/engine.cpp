@@ -683,7 +683,7 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
     std::vector<QueryPlan>& plans = S->lastPlans;
     B.pq.assign(nq, PerQ());
     std::vector<std::vector<infx_cov_cand>> candLocal(nq);
-    std::vector<infx_cov_query> covQ(nq);
+    std::vector<infx_cov_query> covQ(nq); std::vector<std::unique_ptr<infx_cov_query_long>> covL(nq);      // covL: queries beyond the fast Stage-2 envelope
     std::vector<int32_t> covErr(nq, 0);
     const bool covEnabled = ix.cfg.enableCoverage && enable_coverage;
     static const bool dbg = getenv("INFX_DEBUG") != nullptr;
@@ -745,7 +745,7 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
             Sq.idx0 = first2[0]; Sq.idx1 = first2[1];
             if (dbg) { long long d = since(tC); nsSel += d; long long cur = nsSelMax.load(); while (d > cur && !nsSelMax.compare_exchange_weak(cur, d)) {} }
             auto tD = tick();
-            covErr[i] = prepare_cov_query(ix, st, covQ[i]);
+            covErr[i] = prepare_cov_any(ix, st, covQ[i], covL[i]);
             if (dbg) nsCovQ += since(tD);
             if (covErr[i]) continue;
             auto tE = tick();
@@ -754,19 +754,24 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
             for (int32_t d : overlap) push(d, 0.f);
             for (size_t k = 0; k < uniq.size() && k < wmLimit; k++) if (!(del && del[uniq[k]])) push(uniq[k], 0.f);     // a deleted id still uses up its wmLimit slot
             float maxT = ntop ? Sq.stage1[0].score : 1.f;
-            for (size_t k = 0; k < ntop; k++) push(Sq.stage1Doc[k], maxT > 0 ? Sq.stage1[k].score / maxT : 0.f);
+            for (size_t k = 0; k < ntop; k++) {
+                push(Sq.stage1Doc[k], maxT > 0 ? Sq.stage1[k].score / maxT : 0.f);
+                // a document already evaluated as an overlap row: its LCS is read back from the byte span (infx_cov_cand.want_lcs = 2)
+                if (CL.back().want_lcs && std::binary_search(overlap.begin(), overlap.end(), Sq.stage1Doc[k])) CL.back().want_lcs = 2;
+            }
             if (dbg) nsPush += since(tE);
         }
     });
     if (dbg) fprintf(stderr, "[infx] prep2 cpu-ms: merge %.1f wm %.1f select %.1f (max %.2f) covq %.1f push %.1f | wall %.1f\n", nsMerge / 1e6, nsWm / 1e6, nsSel / 1e6, nsSelMax / 1e6, nsCovQ / 1e6, nsPush / 1e6, now_ms() - B.t2);
     // a query outside the Stage-2 envelope is answered as "unsupported" (empty result, flag bit 0); the rest of the batch is unaffected
     for (uint32_t i = 0; i < nq; i++) if (covErr[i]) { B.pq[i].runCov = false; B.pq[i].stage1.clear(); B.pq[i].stage1Doc.clear(); B.pq[i].envelope = true; candLocal[i].clear(); }
-    std::vector<infx_cov_query> covBatch; std::vector<infx_cov_cand>& cands = S->lastCands;
+    std::vector<infx_cov_query> covBatch; std::vector<infx_cov_query_long> covBatchL; std::vector<infx_cov_cand>& cands = S->lastCands;
     size_t ncand = 0;
     for (uint32_t i = 0; i < nq; i++) {
         PerQ& Sq = B.pq[i];
         if (!Sq.runCov) continue;
         Sq.covIndex = (int)covBatch.size(); covBatch.push_back(covQ[i]);
+        if (covL[i]) { covBatch.back().reserved = 1 + (int32_t)covBatchL.size(); covBatchL.push_back(*covL[i]); }
         Sq.candOff = (uint32_t)ncand; Sq.candCount = (uint32_t)candLocal[i].size(); ncand += candLocal[i].size();
     }
     cands.resize(ncand);
@@ -794,7 +799,8 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
     if (!sharded) {     // every candidate is local: score in place
         S->s2Candidates = cands.size();
         if (!cands.empty()) {
-            int32_t rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)cands.size(), cands.data(), outs.data(), wantF ? S->lastFeat.data() : nullptr);
+            int32_t rc = covBatchL.empty() ? INFX_OK : infx_stage2_long_queries(S->stream, (uint32_t)covBatchL.size(), covBatchL.data());
+            if (!rc) rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)cands.size(), cands.data(), outs.data(), wantF ? S->lastFeat.data() : nullptr);
             if (rc) { g_eerr = infx_last_error(); return rc; }
             infx_last_timings(S->stream, nullptr, nullptr, &S->msCov);
         }
@@ -811,7 +817,8 @@ static int32_t ph_stage2(infx_engine* e, infx_session* S, int W, const infx_hit*
         std::vector<int32_t> lfeat;
         if (wantF) lfeat.assign(local.size() * INFX_NFEAT, 0);
         if (!local.empty()) {
-            int32_t rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)local.size(), local.data(), lout.data(), wantF ? lfeat.data() : nullptr);
+            int32_t rc = covBatchL.empty() ? INFX_OK : infx_stage2_long_queries(S->stream, (uint32_t)covBatchL.size(), covBatchL.data());
+            if (!rc) rc = infx_stage2_batch(S->stream, (uint32_t)covBatch.size(), covBatch.data(), (uint32_t)local.size(), local.data(), lout.data(), wantF ? lfeat.data() : nullptr);
             if (rc) { g_eerr = infx_last_error(); return rc; }
             infx_last_timings(S->stream, nullptr, nullptr, &S->msCov);
             for (size_t i = 0; i < local.size(); i++) {

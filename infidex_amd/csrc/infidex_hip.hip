@@ -1345,7 +1345,7 @@ int32_t infx_stage2_long_queries(infx_stream* s, uint32_t n, const infx_cov_quer
     if (!n) return INFX_OK;
     infx_index* ix = s->ix;
     HIPCHK(hipSetDevice(ix->cfg.device));
-    { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
+    // (no pin_reset: this call sits between the phases of a batch, whose pending downloads must survive it; its own upload is staged behind theirs)
     for (uint32_t i = 0; i < n; i++)
         if (q[i].num_tokens < 0 || q[i].num_tokens > INFX_LONGQ_TOKENS || q[i].text_len < 0 || q[i].text_len > INFX_LONGQ_CHARS || q[i].num_fusion_tokens < 0 || q[i].num_fusion_tokens > 2 * INFX_LONGQ_TOKENS)
             return fail(INFX_EUNSUPPORTED, "query exceeds the long Stage-2 envelope%s");

@@ -218,13 +218,16 @@ from tools.synth import Synth
 s = Synth(2, docs=20000); arena, offs = s.docs()
 e = SearchEngine.create_default(device=0); e.index_flat(None, arena, offs, s.field_weights)
 qa, qo = s.queries(300, qseed=9, fuzz=0.3)
-a, o = pack_texts(Synth.texts(qa, qo) + ["qu", "", "zzzzqq"])
+tx = Synth.texts(qa, qo)
+longq = " ".join(dict.fromkeys(w for t in tx[:40] for w in t.split()))      # > 32 distinct words: the long-query launches, in both implementations
+assert len(longq.split()) > 32
+a, o = pack_texts(tx + ["qu", "", "zzzzqq", longq, "x" * 600])
 k, sc, t, c, f = e.search_packed(a, o, 10)
-# an over-long document (260 words: third k_stage2 launch) is ranked like any other; an over-long query is answered as unsupported (flag bit 0)
+# an over-long document (260 words: third k_stage2 launch) is ranked like any other; a query beyond the long envelope (INFX_LONGQ_CHARS) is answered as unsupported (flag bit 0)
 from infidex_amd import Document
 e2 = SearchEngine.create_default(device=0)
 e2.index_documents([Document(0, " ".join("word%d" % i for i in range(260))), Document(1, "word0 word1"), Document(2, "charlie delta"), Document(3, "word0 word1 charlie")])
-a2, o2 = pack_texts(["word0 word1", "charlie delta", "x" * 600])
+a2, o2 = pack_texts(["word0 word1", "charlie delta", "x" * 2100])
 k2, sc2, t2, c2, f2 = e2.search_packed(a2, o2, 5)
 assert not (f2[0] & 8) and 0 in k2[0, :int(c2[0])].tolist() and not (f2[1] & 8) and f2[2] & 1 and c2[2] == 0, (f2, k2)
 np.savez(sys.argv[1], k=k, sc=sc, t=t, c=c, f=f, k2=k2, sc2=sc2, c2=c2, f2=f2)
