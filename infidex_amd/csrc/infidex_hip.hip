@@ -294,6 +294,7 @@ struct infx_stream {
     int32_t* arDoc = nullptr; float* arScore = nullptr; uint8_t* arCls = nullptr; size_t arCap = 0;
     bool accLayoutBad = false;
     unsigned long long* arMask = nullptr; size_t arMaskCap = 0; int maskWords = 0;     // per-row hit masks of the last accumulate launch
+    void* dWideQ = nullptr; size_t capWideQ = 0; uint32_t nWide = 0;                     // queries of the batch with more than 64 reference terms: beyond the masks, never replayed
     uint32_t* arExc = nullptr; uint32_t* exCand = nullptr; infx_hit* exOut = nullptr; size_t exCap = 0;       // tf exception records, candidate lists, replay rows (arena-sized)
     void* exChunks = nullptr; size_t capExChunks = 0; void* exQueries = nullptr; size_t capExQueries = 0; void* exTasks = nullptr; size_t capExTasks = 0; uint32_t* exCounters = nullptr;
     void* dSelOrder = nullptr; size_t capSelOrder = 0;        // k_select_order: the batch's queries by row count, descending
@@ -631,6 +632,16 @@ static int ex_heap_in_regs(const infx_index* ix, int depth) {
     static const bool off = [] { const char* e = getenv("INFX_EX_HEAP_LDS"); return e && e[0] == '1'; }();
     const long long total = std::max<long long>(ix->d.totalDocs, (long long)ix->d.docBase + ix->d.N);
     return (!off && depth <= EXS_MAXDEPTH && total < (1ll << 30)) ? 1 : 0;
+}
+__global__ void k_clear_flags(uint32_t* __restrict__ flags, const uint32_t* __restrict__ list, uint32_t n) { for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) flags[list[i]] = 0u; }
+// After the batch's k_select (with replay flags): the queries beyond the hit masks are selected once more WITHOUT flags — k_select then cuts an over-long
+// plateau by doc id itself instead of leaving it to the replay — and their flags are cleared, so the replay kernels skip them.
+static int32_t select_wide_queries(infx_stream* s, Arena ar, int depth) {
+    if (!s->nWide) return INFX_OK;
+    k_select<<<s->nWide, SEL_THREADS, 0, s->st>>>(ar, s->ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, nullptr, nullptr, nullptr, (const uint32_t*)s->dWideQ);
+    k_clear_flags<<<1, 64, 0, s->st>>>((uint32_t*)s->dExactFlag, (const uint32_t*)s->dWideQ, s->nWide);
+    HIPCHK(hipGetLastError());
+    return INFX_OK;
 }
 static bool exact_possible(infx_stream* s) { return exact_enabled(s->ix) && s->maskWords > 0 && s->ix->nranks == 1 && s->ix->d.docBase == 0; }
 // chunk table of the parallel replay: every query needs at most (containers + reserved rows / 4096 + 2) entries
@@ -1118,7 +1129,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     std::vector<DevRefTerm> refT(std::max<uint32_t>(1, nterms));
     for (uint32_t k = 0; k < nterms; k++) refT[k] = DevRefTerm{terms[k].idf, terms[k].max_score, terms[k].term_id, terms[k].term_id < 0 ? 1u : 0u};
     std::vector<unsigned long long> qbase((size_t)nq + 1);
-    unsigned long long bound = 0; int maxT = 1, useGrp = 0, maxRef = 0;
+    unsigned long long bound = 0; int maxT = 1, useGrp = 0, maxRef = 0, maxRefNarrow = 0; std::vector<uint32_t> wideQ;
     for (uint32_t i = 0; i < nq; i++) {
         const infx_query& Q = q[i];
         if (Q.num_terms > INFX_MAX_QUERY_TERMS || (uint64_t)Q.term_off + Q.num_terms > nterms) return fail(INFX_EINVAL, "bad term range%s");
@@ -1165,6 +1176,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
         if (nEntries > 2048) return fail(INFX_ECAPACITY, "query expands to more than 2048 posting lists (fuzzy member lists); materialise the union on the host%s");
         dq[i] = DevQuery{entryOff, nEntries, Q.mode, Q.prefix_set, Q.depth, Q.n_and, Q.term_off, Q.num_terms};
         maxT = std::max(maxT, (int)nEntries); maxRef = std::max(maxRef, (int)Q.num_terms);
+        if (Q.num_terms > 64) wideQ.push_back(i); else maxRefNarrow = std::max(maxRefNarrow, (int)Q.num_terms);
         if (Q.mode == INFX_MODE_PREFIX) qb = ix->hPsOff[Q.prefix_set + 1] - ix->hPsOff[Q.prefix_set];
         qbase[i] = bound;
         bound += std::min<unsigned long long>(qb, (unsigned long long)ix->d.N);
@@ -1211,8 +1223,12 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
             return fail(INFX_ENOMEM, "arena allocation failed%s");
         s->arCap = n;
     }
-    // per-row hit masks (2 bits per reference term) for the exact Stage-1 replay: kept when every query of the batch has <= 64 terms
-    s->maskWords = !exact_enabled(ix) ? 0 : (maxRef <= 32 ? 1 : (maxRef <= 64 ? 2 : 0));
+    // per-row hit masks (2 bits per reference term) for the exact Stage-1 replay, as wide as the batch's queries of <= 64 terms need.  A query with more terms
+    // (a very long query: words + n-grams, up to 128) has no complete masks and is never replayed — k_select finishes it (select_wide_queries), k_gflag passes it
+    // over — WITHOUT taking the replay away from the other queries of its batch (it used to: one such query switched the masks off for all).
+    s->maskWords = !exact_enabled(ix) || wideQ.size() == nq ? 0 : (maxRefNarrow <= 32 ? 1 : 2);
+    s->nWide = (uint32_t)wideQ.size();
+    if (s->nWide) { GROW(s->dWideQ, s->capWideQ, wideQ.size() * 4); UP(s->dWideQ, wideQ.data(), wideQ.size() * 4); }
     if (s->maskWords && s->arCap * (size_t)s->maskWords > s->arMaskCap) {
         if (s->arMask) { ws_release(s, s->arMask); s->arMask = nullptr; s->arMaskCap = 0; }
         const size_t n = s->arCap * (size_t)s->maskWords;
@@ -1318,6 +1334,7 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     const bool exact = exact_possible(s);
     if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
     k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr, nullptr, select_order(s, nq));
+    if (exact) { int32_t rc_ = select_wide_queries(s, ar, maxDepth); if (rc_) return rc_; }
     if (exact) { int32_t rc_ = enqueue_exact(s, nq, maxDepth); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evS1, s->st));
@@ -1568,6 +1585,7 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, 
         k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr,
                                                 shardNext ? (float*)s->dNext : nullptr, select_order(s, nd));
         if (markTurn) { HIPCHK(hipEventRecord(s->evTurn, s->st)); markTurn = false; }      // the wide phase of this batch ends here
+        if (exact) { int32_t rc_ = select_wide_queries(s, ar, depth); if (rc_) return rc_; }
         if (exact) { int32_t rc_ = enqueue_exact(s, nd, depth); if (rc_) return rc_; }
     }
     if (markTurn) HIPCHK(hipEventRecord(s->evTurn, s->st));
@@ -1883,7 +1901,7 @@ int32_t infx_shard_replay_local(infx_stream* s, int32_t nshards, uint32_t nd, co
         static std::mutex mu; static size_t attr = 0;
         { std::lock_guard<std::mutex> lk(mu); if (lds > 64 * 1024 && lds > attr) { HIPCHK(hipFuncSetAttribute((const void*)k_gflag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = lds; } }
         k_gflag<<<nd, 256, lds, s->st>>>(ix->d, nshards, (int)nd, depth, (int)Dall, (const infx_hit*)s->dFHitsAll, (const uint32_t*)s->dFHcAll, (const float*)s->dAllNext,
-                                        (uint32_t*)s->dExactFlag, (float*)s->dPrior, s->dExactStat + 4, possible ? 1 : 0);
+                                        (uint32_t*)s->dExactFlag, (float*)s->dPrior, s->dExactStat + 4, possible ? 1 : 0, (const uint32_t*)s->dWideQ, s->nWide);
     }
     ExBufs xb{};
     if (possible) {
