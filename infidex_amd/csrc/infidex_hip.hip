@@ -40,6 +40,10 @@ static int32_t fail(int32_t code, const char* fmt, const char* a = "") {
     char buf[512]; snprintf(buf, sizeof buf, fmt, a); g_err = buf; return code;
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(INFX_EHIP, #x ": %s", hipGetErrorString(e_)); } while (0)
+// Start of an API call: select the index's device and drop whatever error an EARLIER runtime call of this thread left behind — the library checks
+// hipGetLastError() after its launches, and a stale error of someone else's call (torch next door leaves "invalid device ordinal" / "peer access already
+// enabled" behind as a matter of course) would otherwise be reported as the failure of the first launch that follows.
+static inline hipError_t enter_device(int device) { const hipError_t e = hipSetDevice(device); (void)hipGetLastError(); return e; }
 
 // ---------------------------------------------------------------------------------------------------------------
 struct DevIndex {
@@ -797,7 +801,7 @@ int32_t infx_create(const infx_config* cfg, infx_index** out) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return fail(INFX_EHIP, "no HIP device available (%s) — the GPU path is mandatory, there is no CPU fallback", hipGetErrorString(e));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(INFX_EINVAL, "bad device ordinal%s");
-    HIPCHK(hipSetDevice(cfg->device));
+    HIPCHK(enter_device(cfg->device));
     infx_index* ix = new infx_index();
     ix->cfg = *cfg;
     int R = cfg->range_docs ? cfg->range_docs : 1024;
@@ -822,7 +826,7 @@ int32_t infx_set_deleted(infx_index* ix, uint32_t total, const uint8_t* deleted)
     if (!ix) return fail(INFX_EINVAL, "null argument%s");
     if (!ix->haveDocs) return fail(INFX_EINVAL, "infx_set_deleted before infx_upload_docs%s");
     if (deleted && total != (uint32_t)ix->d.totalDocs) return fail(INFX_EINVAL, "infx_set_deleted: one flag per global internal id (total_docs) is required%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     HIPCHK(hipDeviceSynchronize());
     if (!deleted) { ix->d.deleted = nullptr; return INFX_OK; }
     bool any = false; for (uint32_t i = 0; i < total && !any; i++) any = deleted[i] != 0;
@@ -838,7 +842,7 @@ int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float
     if (!ix || !doc_len || !doc_key) return fail(INFX_EINVAL, "null argument%s");
     if (deleted && (ix->d.docBase != 0 || (ix->d.totalDocs != 0 && ix->d.totalDocs != (int32_t)N)))
         return fail(INFX_EINVAL, "infx_upload_docs: deleted[] is for unsharded indexes; a shard takes the global flags through infx_set_deleted%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     float *dLen = nullptr, *dNorm = nullptr; int64_t* dKey = nullptr; uint64_t* dTO = nullptr; uint16_t* dTx = nullptr;
     HIPCHK(dalloc(ix, &dNorm, N)); HIPCHK(dalloc(ix, &dKey, N)); HIPCHK(dalloc(ix, &dLen, N));
     HIPCHK(hipMemcpy(dLen, doc_len, (size_t)N * 4, hipMemcpyHostToDevice));
@@ -870,7 +874,7 @@ int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float
 int32_t infx_upload_postings(infx_index* ix, uint32_t T, const uint64_t* offs, const int32_t* doc_ids, const uint8_t* tf, const int32_t* df) {
     if (!ix || !offs || !df) return fail(INFX_EINVAL, "null argument%s");
     if (!ix->haveDocs) return fail(INFX_EINVAL, "infx_upload_docs must precede infx_upload_postings (range count)%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     uint64_t P = offs[T];
     uint64_t* dOff = nullptr; int32_t* dDoc = nullptr; uint8_t* dW = nullptr;
     // padded layout (k_pad_lists): list t lives at [off2[t], off2[t] + len_t), the rest of its 4-aligned slot holds sentinels
@@ -931,7 +935,7 @@ int32_t infx_upload_postings(infx_index* ix, uint32_t T, const uint64_t* offs, c
 
 int32_t infx_upload_prefix_docsets(infx_index* ix, uint32_t nsets, const uint64_t* offs, const int32_t* docs) {
     if (!ix || (nsets && !offs)) return fail(INFX_EINVAL, "null argument%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     uint64_t* dOff = nullptr; int32_t* dDocs = nullptr;
     uint64_t tot = nsets ? offs[nsets] : 0;
     HIPCHK(dalloc(ix, &dOff, (size_t)nsets + 1)); HIPCHK(dalloc(ix, &dDocs, (size_t)tot));
@@ -978,7 +982,7 @@ int32_t infx_set_shard_comm(infx_index* ix, const void* id128) {
     if (!ix || !id128) return fail(INFX_EINVAL, "null argument%s");
     if (!rccl_api().ok) return fail(INFX_ENCCL, "RCCL unavailable: %s", rccl_api().why);
     if (ix->comm) return fail(INFX_EINVAL, "this index already joined a communicator%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     ncclUniqueId id; std::memcpy(&id, id128, sizeof id);
     NCCLCHK(rccl_api().init(&ix->comm, ix->nranks, id, ix->rank));
     return INFX_OK;
@@ -987,7 +991,7 @@ int32_t infx_stream_comm(infx_stream* s, const void* id128) {
     if (!s || !id128) return fail(INFX_EINVAL, "null argument%s");
     if (!rccl_api().ok) return fail(INFX_ENCCL, "RCCL unavailable: %s", rccl_api().why);
     if (s->comm) return fail(INFX_EINVAL, "this stream already joined a communicator%s");
-    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    HIPCHK(enter_device(s->ix->cfg.device));
     ncclUniqueId id; std::memcpy(&id, id128, sizeof id);
     NCCLCHK(rccl_api().init(&s->comm, s->ix->nranks, id, s->ix->rank));
     return INFX_OK;
@@ -1010,7 +1014,7 @@ int32_t infx_comm_allgather(infx_stream* s, const void* send, void* recv, uint64
 }
 int32_t infx_stream_scratch(infx_stream* s, int32_t slot, uint64_t bytes, void** out) {
     if (!s || !out || slot < 0 || slot >= 16) return fail(INFX_EINVAL, "bad scratch arguments%s");
-    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    HIPCHK(enter_device(s->ix->cfg.device));
     if (bytes > s->capScratch[slot]) {
         if (s->unsynced) { int32_t rc_ = stream_sync(s); if (rc_) return rc_; }      // work queued on the old buffer
         GROW(s->scratch[slot], s->capScratch[slot], (size_t)bytes);
@@ -1020,7 +1024,7 @@ int32_t infx_stream_scratch(infx_stream* s, int32_t slot, uint64_t bytes, void**
 int32_t infx_stream_copy(infx_stream* s, void* dst, const void* src, uint64_t bytes) {
     if (!s || (bytes && (!dst || !src))) return fail(INFX_EINVAL, "null argument%s");
     if (!bytes) return INFX_OK;
-    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    HIPCHK(enter_device(s->ix->cfg.device));
     const bool dd = is_device_ptr(dst), sd = is_device_ptr(src);
     if (dd && sd) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->st)); s->unsynced = true; return INFX_OK; }
     if (dd) return up(s, dst, src, bytes);
@@ -1032,7 +1036,7 @@ int32_t infx_stream_unpack(infx_stream* s, const void* src, uint64_t stride, int
     if (!s || !src || nranks < 1 || nparts < 1 || nparts > 4 || !part_bytes || !dsts) return fail(INFX_EINVAL, "bad unpack arguments%s");
     uint64_t tot = 0; for (int p = 0; p < nparts; p++) { if (!dsts[p] || (part_bytes[p] & 3)) return fail(INFX_EINVAL, "unpack parts are whole 32-bit words%s"); tot += part_bytes[p]; }
     if (tot > stride || (stride & 3)) return fail(INFX_EINVAL, "unpack parts exceed the block%s");
-    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    HIPCHK(enter_device(s->ix->cfg.device));
     if (is_device_ptr(src)) {
         UnpackArgs a{}; a.src = (const uint32_t*)src; a.strideW = stride >> 2; a.nranks = nranks; a.nparts = nparts;
         uint64_t off = 0; for (int p = 0; p < nparts; p++) { a.offW[p] = off >> 2; a.lenW[p] = part_bytes[p] >> 2; a.dst[p] = (uint32_t*)dsts[p]; off += part_bytes[p]; }
@@ -1048,12 +1052,12 @@ int32_t infx_stream_unpack(infx_stream* s, const void* src, uint64_t stride, int
 }
 int32_t infx_stream_fill0(infx_stream* s, void* dev, uint64_t bytes) {
     if (!s || (bytes && !dev)) return fail(INFX_EINVAL, "null argument%s");
-    if (bytes) { HIPCHK(hipSetDevice(s->ix->cfg.device)); HIPCHK(hipMemsetAsync(dev, 0, bytes, s->st)); s->unsynced = true; }
+    if (bytes) { HIPCHK(enter_device(s->ix->cfg.device)); HIPCHK(hipMemsetAsync(dev, 0, bytes, s->st)); s->unsynced = true; }
     return INFX_OK;
 }
 int32_t infx_stream_wait(infx_stream* s) {
     if (!s) return fail(INFX_EINVAL, "null argument%s");
-    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    HIPCHK(enter_device(s->ix->cfg.device));
     return stream_sync(s);
 }
 
@@ -1064,7 +1068,7 @@ int32_t infx_stream_native(infx_stream* s, void** hip_stream) {
 
 int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     if (!ix || !out) return fail(INFX_EINVAL, "null argument%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     infx_stream* s = new infx_stream(); s->ix = ix;
     HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
     s->stMain = s->st;
@@ -1300,7 +1304,7 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     infx_index* ix = s->ix;
     if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
     if (nq == 0) return INFX_OK;
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     { int32_t rc_ = acc_enqueue(s, nq, q, nterms, terms, extra_n, extra_docs); if (rc_) return rc_; }
     uint32_t ovf = 0; std::vector<unsigned long long> qbytes(nq);
@@ -1319,7 +1323,7 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     if (nq == 0) return INFX_OK;
     if (nq != s->lastNq) return fail(INFX_EINVAL, "infx_stage1_select must follow infx_stage1_accumulate of the same batch%s");
     infx_index* ix = s->ix;
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     std::vector<SelRule> rules(nq);
     int maxDepth = 0;
@@ -1361,7 +1365,7 @@ int32_t infx_stage2_long_queries(infx_stream* s, uint32_t n, const infx_cov_quer
     s->nLongQ = 0;
     if (!n) return INFX_OK;
     infx_index* ix = s->ix;
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     // (no pin_reset: this call sits between the phases of a batch, whose pending downloads must survive it; its own upload is staged behind theirs)
     for (uint32_t i = 0; i < n; i++)
         if (q[i].num_tokens < 0 || q[i].num_tokens > INFX_LONGQ_TOKENS || q[i].text_len < 0 || q[i].text_len > INFX_LONGQ_CHARS || q[i].num_fusion_tokens < 0 || q[i].num_fusion_tokens > 2 * INFX_LONGQ_TOKENS)
@@ -1380,7 +1384,7 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     if (ncand == 0) return INFX_OK;
     infx_index* ix = s->ix;
     if (!ix->haveDocs || !ix->d.text) return fail(INFX_EINVAL, "document text not uploaded%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     for (uint32_t i = 0; i < nq; i++) {
         if (q[i].reserved != 0) { if (q[i].reserved < 0 || (uint32_t)q[i].reserved > s->nLongQ) return fail(INFX_EINVAL, "query refers to a missing long-query record (infx_stage2_long_queries)%s"); continue; }
@@ -1415,7 +1419,7 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
 
 int32_t infx_upload_wordmatcher(infx_index* ix, uint64_t n_exact, const int32_t* exact_docs, uint64_t n_ld1, const int32_t* ld1_docs) {
     if (!ix || (n_exact && !exact_docs) || (n_ld1 && !ld1_docs)) return fail(INFX_EINVAL, "null argument%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     int32_t *dE = nullptr, *dL = nullptr;
     HIPCHK(dalloc(ix, &dE, (size_t)n_exact + 1)); HIPCHK(dalloc(ix, &dL, (size_t)n_ld1 + 1));
     if (n_exact) HIPCHK(hipMemcpy(dE, exact_docs, (size_t)n_exact * 4, hipMemcpyHostToDevice));
@@ -1454,7 +1458,7 @@ int32_t infx_upload_wm_dictionary(infx_index* ix, uint32_t n_exact, const uint32
     if (ix->haveDict) return fail(INFX_EINVAL, "WordMatcher dictionary already uploaded%s");
     if (min_ld1 < 1 || max_ld1 < min_ld1 || 3 + 2 * max_ld1 > INFX_MAX_WM_LISTS) return fail(INFX_EINVAL, "bad LD1 word-length window%s");
     for (uint32_t i = 0; i < n_affix; i++) if (affix_fwd[i] >= n_words || affix_rev[i] >= n_words) return fail(INFX_EINVAL, "affix word id out of range%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     if (!ix->lk) ix->lk = new DevLookup{};
     DevLookup& K = *ix->lk;
     { int32_t rc_ = dict_upload(ix, K.exact, n_exact, exact_key_offs, exact_chars, exact_list_offs, ix->nWmExact); if (rc_) return rc_; }
@@ -1482,7 +1486,7 @@ int32_t infx_upload_term_trie(infx_index* ix, uint32_t n_nodes, const uint32_t* 
     for (uint32_t k = 0; k < ne; k++) if (edge_child[k] >= n_nodes) return fail(INFX_EINVAL, "edge child out of range%s");
     std::vector<uint32_t> rank(n_terms, 0xFFFFFFFFu);
     for (uint32_t i = 0; i < n_terms; i++) { if (sorted_terms[i] >= n_terms || rank[sorted_terms[i]] != 0xFFFFFFFFu) return fail(INFX_EINVAL, "sorted_terms is not a permutation%s"); rank[sorted_terms[i]] = i; }
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     if (!ix->lk) ix->lk = new DevLookup{};
     DevLookup& K = *ix->lk;
     { int32_t rc_ = dcopy(ix, &K.rEdgeStart, edge_start, (size_t)n_nodes + 1); if (rc_) return rc_; }
@@ -1500,7 +1504,7 @@ int32_t infx_ld1_expand(infx_stream* s, uint32_t nwords, const uint32_t* word_of
     if (nwords == 0) return INFX_OK;
     infx_index* ix = s->ix;
     if (!ix->haveTrie) return fail(INFX_EINVAL, "infx_upload_term_trie has not been called%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     PlanStream plan(s);
     const size_t nch = word_offs[nwords];
@@ -1740,7 +1744,7 @@ int32_t infx_wm_lookup_debug(infx_stream* s, const infx_cov_query* cq, infx_wm_l
     if (cq->text_len > INFX_MAX_QUERY_CHARS || cq->num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS) return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope%s");
     if (words * (uint32_t)(3 + 2 * ix->lk->maxLd1) > INFX_MAX_WM_LISTS) return fail(INFX_ECAPACITY, "too many words for the device WordMatcher lookup%s");
     if ((uint64_t)words * WM_AFFIX_CAP > owned_cap) return fail(INFX_EINVAL, "owned_out too small%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     infx_fused_query fq{}; fq.dev = -1; fq.flags = INFX_FQ_COV | INFX_FQ_WMDEV; fq.max_results = 1; fq.reserved = 0;
     GROW(s->dFQ, s->capFQ, sizeof(infx_fused_query));
@@ -1772,7 +1776,7 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
     if (nq == 0) return INFX_OK;
     { int32_t rc_ = fused_check_queries(ix, nd, nq, fq, cq, nlists, lists, owned_n, depth, max_results, s->nLongQ); if (rc_) return rc_; }
     for (uint32_t i = 0; i < nd; i++) if (q[i].depth != depth) return fail(INFX_EINVAL, "all queries of a fused batch share one depth%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     // Turnstile.  k_accumulate and k_select fill the GPU on their own; the replay, candidate assembly and Stage 2 behind them are narrow.  Sessions that
     // submit together run their wide kernels against each other and then sit in their narrow phases together — convoys that leave the GPU half empty (the
@@ -1812,7 +1816,7 @@ int32_t infx_shard_select(infx_stream* s, uint32_t nd, const infx_counts* global
     if (nd == 0) return INFX_OK;
     if (nd != s->lastNq) return fail(INFX_EINVAL, "infx_shard_select must follow infx_stage1_accumulate of the same batch%s");
     infx_index* ix = s->ix;
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     UPX(s->dCounts, global_counts, (size_t)nd * INFX_NCLASS * 4);         // the tier rules see the GLOBAL cardinalities (quirk Q11); host or device memory
     { int32_t rc_ = fused_enqueue_select(s, nd, depth, true); if (rc_) return rc_; }
@@ -1836,7 +1840,7 @@ int32_t infx_shard_stage2(infx_stream* s, int32_t nshards, uint32_t nd, const in
     if (!ix->haveDocs || !ix->d.text || !ix->d.docKeyAll) return fail(INFX_EINVAL, "index not uploaded%s");
     if (nq == 0) return INFX_OK;
     { int32_t rc_ = fused_check_queries(ix, nd, nq, fq, cq, nlists, lists, owned_n, depth, max_results, s->nLongQ); if (rc_) return rc_; }
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     const size_t nh = (size_t)nshards * std::max<size_t>(1, nd) * depth;
     GROW(s->dFHitsAll, s->capFHitsAll, nh * sizeof(infx_hit));
@@ -1857,7 +1861,7 @@ int32_t infx_shard_finalize(infx_stream* s, uint32_t nq, const infx_cov_out* mer
     if (!s || (nq && (!merged_outs || !out_keys || !out_scores || !out_counts))) return fail(INFX_EINVAL, "null argument%s");
     if (nq == 0) return INFX_OK;
     if (nq != s->fusedNq || depth != s->fusedDepth) return fail(INFX_EINVAL, "infx_shard_finalize must follow infx_shard_stage2 of the same batch%s");
-    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    HIPCHK(enter_device(s->ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     UPX(s->dCovO, merged_outs, (size_t)nq * 2 * depth * sizeof(infx_cov_out));
     { int32_t rc_ = fused_enqueue_finalize(s, nq, depth, max_results, out_ties != nullptr); if (rc_) return rc_; }
@@ -1881,7 +1885,7 @@ int32_t infx_shard_replay_local(infx_stream* s, int32_t nshards, uint32_t nd, co
     if (!s->shSelected || nd != s->shNd || depth != s->shDepth) return fail(INFX_EINVAL, "infx_shard_replay_local must follow infx_shard_select of the same batch%s");
     if (nshards != ix->nranks) return fail(INFX_EINVAL, "nshards differs from infx_set_shard%s");
     if (ix->nranks > 1 && (ix->d.docBase & 0xFFFF)) return fail(INFX_EINVAL, "exact replay across shards needs shard boundaries at multiples of 65536 documents (whole Roaring containers)%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     const uint32_t Dall = pow2_at_least((uint32_t)nshards * (uint32_t)depth, 8);
     if (Dall > 16384) return fail(INFX_ECAPACITY, "shards x depth exceeds the in-LDS merge (16384 rows)%s");
@@ -1935,7 +1939,7 @@ int32_t infx_shard_replay_blob(infx_stream* s, void* dst, uint64_t padded_bytes)
     const size_t have = shx_blob_bytes(s->shNd, s->shHead[1], s->shHead[2]);
     if (!s->shNd) return INFX_OK;
     if (padded_bytes < have) return fail(INFX_EINVAL, "padded size below this shard's blob%s");
-    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    HIPCHK(enter_device(s->ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     DOWNX(dst, s->shBlob, have);       // the padding beyond `have` is never read (the header says how much is valid)
     SYNC();
@@ -1949,7 +1953,7 @@ int32_t infx_shard_replay_merge(infx_stream* s, int32_t nshards, uint32_t nd, co
     infx_index* ix = s->ix;
     if (!s->shSelected || nd != s->shNd || depth != s->shDepth || nshards != ix->nranks) return fail(INFX_EINVAL, "infx_shard_replay_merge must follow infx_shard_replay_local of the same batch%s");
     if (padded_bytes < shx_blob_bytes(nd, 0, 0)) return fail(INFX_EINVAL, "blob size below the header%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     GROW(s->dAllBlobs, s->capAllBlobs, (size_t)nshards * padded_bytes);
     UPX(s->dAllBlobs, all_blobs, (size_t)nshards * padded_bytes);
@@ -1973,7 +1977,7 @@ int32_t infx_shard_replay_chain(infx_stream* s, uint32_t nd, const uint32_t* nee
     infx_index* ix = s->ix;
     if (!s->shSelected || nd != s->shNd || depth != s->shDepth) return fail(INFX_EINVAL, "infx_shard_replay_chain must follow infx_shard_select of the same batch%s");
     if (!shard_exact_possible(s)) return fail(INFX_EINVAL, "no hit masks were kept for this batch: nothing to replay%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     const int depthCap = ix->cfg.max_depth;
     if (depth != depthCap) return fail(INFX_EINVAL, "the chained replay exchanges heaps of infx_config.max_depth entries: search with that depth%s");
@@ -1994,7 +1998,7 @@ int32_t infx_shard_replay_chain(infx_stream* s, uint32_t nd, const uint32_t* nee
 
 int32_t infx_upload_doc_keys_all(infx_index* ix, uint32_t total_docs, const int64_t* keys) {
     if (!ix || (total_docs && !keys)) return fail(INFX_EINVAL, "null argument%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     int64_t* d = nullptr;
     HIPCHK(dalloc(ix, &d, (size_t)total_docs + 1));
     if (total_docs) HIPCHK(hipMemcpy(d, keys, (size_t)total_docs * 8, hipMemcpyHostToDevice));
@@ -2006,7 +2010,7 @@ int32_t infx_fused_debug(infx_stream* s, infx_hit* s1, uint32_t* s1_counts, infx
                          uint32_t* cand_counts, uint32_t* run_cov, int32_t* idx01) {
     if (!s || !s->fusedNq) return fail(INFX_EINVAL, "no fused batch to read back%s");
     if (feat && !s->fusedDebug) return fail(INFX_EINVAL, "the last fused batch ran without want_debug%s");
-    HIPCHK(hipSetDevice(s->ix->cfg.device));
+    HIPCHK(enter_device(s->ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     const uint32_t nq = s->fusedNq; const size_t depth = (size_t)s->fusedDepth, ncand = (size_t)nq * 2 * depth;
     std::vector<FusedMeta> metas(nq);
@@ -2058,7 +2062,7 @@ static int32_t union_build_impl(infx_stream* s, uint32_t nv, const uint32_t* mem
     infx_index* ix = s->ix;
     if (!ix->havePostings || !ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
     if (nwords && !ix->haveTrie) return fail(INFX_EINVAL, "infx_upload_term_trie has not been called%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     PlanStream plan(s);
     const int nR = ix->d.nRanges;
@@ -2134,7 +2138,7 @@ int32_t infx_last_replay_stats(infx_stream* s, float* ms, uint32_t* why3) {
 // acc_div (stage1.hip.inc) against the compiler's fp32 division on the device: every tf byte x 65 536 denominators; *mismatches must come back 0
 int32_t infx_selftest_div(int32_t device, uint32_t* mismatches) {
     if (!mismatches) return fail(INFX_EINVAL, "null argument%s");
-    HIPCHK(hipSetDevice(device));
+    HIPCHK(enter_device(device));
     uint32_t* d = nullptr; HIPCHK(hipMalloc((void**)&d, 4)); HIPCHK(hipMemset(d, 0, 4));
     k_div_selftest<<<dim3(256, 256), 256>>>(d);
     hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(mismatches, d, 4, hipMemcpyDeviceToHost); (void)hipFree(d);
@@ -2168,7 +2172,7 @@ int32_t infx_last_alg_bytes(infx_stream* s, uint64_t* bytes) {
 // ---- Infiscript post-filter + facets (config 5) --------------------------------------------------------------------------------------
 int32_t infx_upload_column(infx_index* ix, uint32_t col, uint32_t total_docs, const uint32_t* codes, uint32_t num_values) {
     if (!ix || col >= FILT_MAXCOL || (total_docs && !codes)) return fail(INFX_EINVAL, "bad column arguments%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     if (ix->haveDocs && (uint64_t)total_docs < (uint64_t)ix->d.docBase + (uint64_t)ix->d.N) return fail(INFX_EINVAL, "a column needs one code per GLOBAL internal id covering this shard%s");
     HIPCHK(hipDeviceSynchronize());                      // exclusive call (the reference's write lock): no search is in flight
     uint32_t* d = const_cast<uint32_t*>(ix->colCodes[col]);
@@ -2198,7 +2202,7 @@ int32_t infx_filter_create(infx_index* ix, uint32_t nops, const infx_filter_op* 
         if (L.col != 0xFFFFFFFFu && (L.col >= FILT_MAXCOL || !ix->colCodes[L.col])) return fail(INFX_EINVAL, "filter refers to a column that was not uploaded%s");
         if ((uint64_t)L.table_off + (L.num_values + 31) / 32 > ntable_words) return fail(INFX_EINVAL, "filter leaf table out of range%s");
     }
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     infx_filter* f = new infx_filter(); f->ix = ix; f->nops = nops; f->nleaves = nleaves;
     auto bail = [&](int32_t rc) { infx_filter_destroy(f); return rc; };
     if (hipMalloc(&f->dOps, nops * sizeof(infx_filter_op)) != hipSuccess || hipMalloc(&f->dLeaves, std::max<size_t>(1, nleaves) * sizeof(infx_filter_leaf)) != hipSuccess ||
@@ -2219,7 +2223,7 @@ int32_t infx_filter_count(infx_stream* s, infx_filter* f, uint32_t* count) {
     if (!s || !f || !count || f->ix != s->ix) return fail(INFX_EINVAL, "bad filter arguments%s");
     infx_index* ix = s->ix;
     if (!ix->haveDocs) return fail(INFX_EINVAL, "index not uploaded%s");
-    HIPCHK(hipSetDevice(ix->cfg.device));
+    HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
     for (int c = 0; c < FILT_MAXCOL; c++)       // columns are indexed by GLOBAL internal id: every uploaded column must cover this shard
         if (ix->colCodes[c] && (uint64_t)ix->colDocs[c] < (uint64_t)ix->d.docBase + (uint64_t)ix->d.N) return fail(INFX_EINVAL, "a column holds fewer rows than this shard's documents%s");
