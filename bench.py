@@ -130,6 +130,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("INFX_DIST_BACKEND", "nccl")     # "gloo" lets two ranks share one GPU when testing the sharded flow
+        if os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]) == os.environ["WORLD_SIZE"]:
+            # all ranks on this node: the gloo groups of the run (plan exchange, the per-session groups of a gloo run) talk over loopback — gloo otherwise looks the
+            # container's hostname up to pick an interface, and that name need not resolve
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         local_rank = local_rank % max(1, torch.cuda.device_count())
         if torch.cuda.is_available() or backend == "nccl":       # (the launch-only CPU test runs over gloo without a device)
             torch.cuda.set_device(local_rank)

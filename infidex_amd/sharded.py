@@ -473,7 +473,17 @@ class ShardedSearcher:
             if self.native:
                 cc, keep = native_comm(engine, comm, session=s, group=(comm.dist.new_group(backend="gloo") if gloo and K > 1 else None))
                 self.ccomms.append(cc); self._keep.append(keep)
-            self.plan_groups.append(comm.dist.new_group(backend="gloo") if self.partition_planning else None)      # (collective: every rank creates the same groups in the same order)
+            g = None
+            if self.partition_planning:      # (collective: every rank creates the same groups in the same order)
+                try:
+                    g = comm.dist.new_group(backend="gloo")
+                except Exception as ex:      # no gloo transport on this host (the same on every rank of a node): every rank plans every query, as without the exchange
+                    import sys
+                    print(f"[infidex] plan exchange off: gloo group could not be created ({ex})", file=sys.stderr)
+                    self.partition_planning = False
+            self.plan_groups.append(g)
+        if not self.partition_planning:
+            self.plan_groups = [None] * len(self.sessions)
         self.plan_group = self.plan_groups[0]
         on_dev = comm.device.type == "cuda" and comm.dist.get_backend() == "nccl"
         self.X = _DistX(comm, _DevBufs(comm.device) if on_dev else _HostBufs())
