@@ -327,7 +327,7 @@ struct infx_stream {
     void *dLWordOff = nullptr, *dLChars = nullptr, *dLMembers = nullptr, *dLCount = nullptr; size_t capLWordOff = 0, capLChars = 0, capLMembers = 0, capLCount = 0;   // infx_ld1_expand
 };
 
-#define S2_HUGE_POOL_U16 (32u << 20)      // token-table pool of k_stage2's over-long-document pass: 64 MB per stream (a 700-word row takes 5.7 KB, a 32 768-token one 265 KB)
+#define S2_HUGE_POOL_U16 (32u << 20)      // token-table pool of k_stage2's over-long-document pass: 64 MB per stream (a 700-word row takes 7.1 KB, a 32 768-token one 332 KB)
 static int32_t grow(infx_stream* s, void** p, size_t* cap, size_t need);
 static int32_t s2_huge_ready(infx_stream* s) {      // pool + bump counter of the over-long-document pass (allocated at the stream's first Stage-2 launch)
     int32_t rc = grow(s, &s->dHugeWs, &s->capHugeWs, (size_t)S2_HUGE_POOL_U16 * 2); if (rc) return rc;
