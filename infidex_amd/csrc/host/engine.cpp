@@ -155,11 +155,13 @@ struct infx_engine {
     // depends on the sizes of the affix ranges (config 3: 37 ms of 16 threads per batch; a word-count model sent it to the host and halved the rate).
     // LD1 expansion: by cost.  The host walk is predictable (~21 us of one core per unknown word, spread over the planner threads); k_ld1 is one latency-bound wave
     // per word whose result the host WAITS for, and behind five other batches' streaming kernels that wait is ~15 ms (0.2 ms on an idle GPU): with cores to spare
-    // the host is faster (10 M documents, 16 CPUs: 74.8 k against 68.7 k queries/s); the device takes the batch when the estimated host time exceeds a quarter of
-    // the planner threads' time in a 10-ms batch interval — two threads per rank on an 8-GPU node, or thousands of unknown words.  INFX_DEVICE_LOOKUPS=1 pins the
-    // device (the GPU test suite does), INFX_HOST_LOOKUPS=1 keeps everything on the host (no upload).
+    // the host is faster for a few hundred words (config 4, ~220 unknown words per batch, 10 M documents, 16 CPUs: 74.8 k against 68.7 k queries/s); the device takes
+    // the batch when the estimated host time exceeds a tenth of the planner threads' time in a 10-ms batch interval — two threads per rank on an 8-GPU node, or about
+    // a thousand unknown words: config 3 (every query misspelt, ~960 words per batch) runs 68.0 k against 65.7 k queries/s with the expansion on the device (fused into
+    // the union build: one wait) at four sessions, 43.5 k against 39.7 k at one (round 5, profiles/r05_bench_cfg3_device_ld1_*.json; the threshold was 2.5 x before and
+    // sent config 3 to the host).  INFX_DEVICE_LOOKUPS=1 pins the device (the GPU test suite does), INFX_HOST_LOOKUPS=1 keeps everything on the host (no upload).
     bool ld1Pinned = false;
-    bool ld1_on_device(double estThreadMs) const { return devLookups && (ld1Pinned || estThreadMs > 2.5 * (double)std::max(1, threads)); }
+    bool ld1_on_device(double estThreadMs) const { return devLookups && (ld1Pinned || estThreadMs > 1.0 * (double)std::max(1, threads)); }
     bool lookups_on_device(double) const { return devLookups; }
     int threads = 1;
     int buildThreads = 0;             // > 0: threads of the index build only (infx_engine_set_build_threads)
