@@ -237,3 +237,38 @@ def test_shards_are_whole_containers():
         assert all(b % 65536 == 0 or b == 150000 for b, _ in spans), spans
         if W == 5:
             assert sum(1 for _, n in spans if n == 0) == 2
+
+
+def test_plan_exchange_edge_batches_in_one_process():
+    """The plan exchange between two host-only engines of one process (no transport): empty batches, single queries, empty slices, a slice that is the whole
+    batch — the importer's digests equal the ones it computes itself, and every exchanged query is counted."""
+    import ctypes as C
+    from infidex_amd import SearchEngine
+    from infidex_amd.engine import _p, pack_texts
+    from tools.synth import Synth
+    s = Synth(4, docs=5000); arena, offs = s.docs()
+    a = SearchEngine.create_default(device=-1); a.index_flat(None, arena, offs, s.field_weights)
+    b = SearchEngine.create_default(device=-1); b.index_flat(None, arena, offs, s.field_weights)
+    c = SearchEngine.create_default(device=-1); c.index_flat(None, arena, offs, s.field_weights)      # never sees an exchange: the reference digests
+    L = a.L; L.infx_session_prefetch_collect.restype = C.c_int64
+    sa = C.c_void_p(); sb = C.c_void_p(); sc = C.c_void_p()
+    assert L.infx_engine_default_session(a.h, C.byref(sa)) == 0 and L.infx_engine_default_session(b.h, C.byref(sb)) == 0 and L.infx_engine_default_session(c.h, C.byref(sc)) == 0
+    qa, qo = s.queries(6, qseed=2, fuzz=0.5)
+    texts = Synth.texts(qa, qo)
+    for batch, (begin, end) in [([], (0, 0)), (texts[:1], (0, 1)), (texts[:1], (0, 0)), (texts[:1], (1, 1)), (texts, (0, 6)), (texts, (2, 5)), (texts, (6, 6)), (texts[:2] + [""], (2, 3))]:
+        qa2, qo2 = pack_texts(batch); nq = len(batch)
+        ref = np.zeros(max(nq, 1), np.uint64); used = C.c_uint32(9)
+        assert L.infx_session_plan_digest(sc, nq, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), 500, _p(ref, C.c_uint64), C.byref(used)) == 0 and used.value == 0
+        n = L.infx_session_prefetch_collect(sa, nq, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), begin, end, 500); assert n > 0, (batch, begin, end)
+        blob = np.zeros(n, np.uint8); assert L.infx_session_prefetch_blob(sa, _p(blob, C.c_uint8), C.c_int64(n)) == 0
+        assert L.infx_session_prefetch_collect(sb, nq, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), 0, 0, 500) > 0      # the importer's own (empty) slice: a rank collects before it imports
+        assert L.infx_session_prefetch_import(sb, _p(blob, C.c_uint8), C.c_int64(n)) == 0, a.L.infx_engine_last_error()
+        got = np.zeros(max(nq, 1), np.uint64)
+        assert L.infx_session_plan_digest(sb, nq, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), 500, _p(got, C.c_uint64), C.byref(used)) == 0
+        assert used.value == end - begin and np.array_equal(got[:nq], ref[:nq]), (batch, begin, end, used.value)
+        # another depth than the plans were made for: nothing of the exchange is used
+        assert L.infx_session_plan_digest(sb, nq, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), 200, _p(got, C.c_uint64), C.byref(used)) == 0 and used.value == 0
+    # a slice outside the batch is refused by the collector
+    qa2, qo2 = pack_texts(texts)
+    assert L.infx_session_prefetch_collect(sa, 6, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), 4, 7, 500) < 0
+    assert L.infx_session_prefetch_collect(sa, 6, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), 5, 4, 500) < 0
