@@ -272,3 +272,74 @@ def test_plan_exchange_edge_batches_in_one_process():
     qa2, qo2 = pack_texts(texts)
     assert L.infx_session_prefetch_collect(sa, 6, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), 4, 7, 500) < 0
     assert L.infx_session_prefetch_collect(sa, 6, _p(qa2, C.c_uint16), _p(qo2, C.c_uint64), 5, 4, 500) < 0
+
+
+def _blob_hash(b: bytes) -> int:      # bytes_hash of csrc/host/engine.cpp (the plan section's checksum), restated
+    M = (1 << 64) - 1
+    h = (0x9E3779B97F4A7C15 ^ len(b)) & M
+    i = 0
+    while i + 8 <= len(b):
+        h = ((h ^ int.from_bytes(b[i:i + 8], "little")) * 0xFF51AFD7ED558CCD) & M; h ^= h >> 32; i += 8
+    for c in b[i:]:
+        h = ((h ^ c) * 1099511628211) & M
+    return h ^ (h >> 29)
+
+
+def _plan_section_start(blob: bytes) -> int:      # skips the LD1 and WordMatcher sections (layout: infx_session_prefetch_collect)
+    import struct
+    o = 8
+    (n,) = struct.unpack_from("<I", blob, o); o += 4
+    for _ in range(n):
+        (wl,) = struct.unpack_from("<H", blob, o); o += 2 + 2 * wl
+        (nm,) = struct.unpack_from("<I", blob, o); o += 4 + 4 * nm
+    (n,) = struct.unpack_from("<I", blob, o); o += 4
+    for _ in range(n):
+        (tl,) = struct.unpack_from("<H", blob, o); o += 2 + 2 * tl
+        (nl,) = struct.unpack_from("<I", blob, o); o += 4 + 16 * nl
+        (no,) = struct.unpack_from("<I", blob, o); o += 4 + 4 * no
+    return o
+
+
+def test_damaged_plan_records_are_refused_not_believed():
+    """The plan section is checksummed (a damaged blob is refused at import); behind the checksum every record is still range-checked where it is parsed.
+    800 single-byte corruptions of the plan section WITH a recomputed checksum: import or the parse (through infx_session_plan_digest) reports an error or the
+    record happens to stay well-formed — nothing crashes, and a clean blob is accepted afterwards."""
+    import ctypes as C
+    import random
+    from infidex_amd import SearchEngine
+    from infidex_amd.engine import _p, pack_texts
+    from tools.synth import Synth
+    s = Synth(4, docs=5000); arena, offs = s.docs()
+    a = SearchEngine.create_default(device=-1); a.index_flat(None, arena, offs, s.field_weights)
+    b = SearchEngine.create_default(device=-1); b.index_flat(None, arena, offs, s.field_weights)
+    L = a.L; L.infx_session_prefetch_collect.restype = C.c_int64
+    sa = C.c_void_p(); sb = C.c_void_p()
+    assert L.infx_engine_default_session(a.h, C.byref(sa)) == 0 and L.infx_engine_default_session(b.h, C.byref(sb)) == 0
+    qa, qo = s.queries(40, qseed=4, fuzz=0.5)
+    qa, qo = pack_texts(Synth.texts(qa, qo) + ["", "qu", " ".join("w%dq" % i for i in range(40)), "x" * 600]); nq = len(qo) - 1
+    n = L.infx_session_prefetch_collect(sa, nq, _p(qa, C.c_uint16), _p(qo, C.c_uint64), 0, nq, 500); assert n > 0
+    blob = np.zeros(n, np.uint8); assert L.infx_session_prefetch_blob(sa, _p(blob, C.c_uint8), C.c_int64(n)) == 0
+    raw = blob.tobytes(); start = _plan_section_start(raw)
+    assert _blob_hash(raw[start:-8]) == int.from_bytes(raw[-8:], "little")      # the restated checksum is the library's
+    rng = random.Random(1); refused_import = refused_parse = accepted = 0
+    out = np.zeros(nq, np.uint64); used = C.c_uint32(0)
+    for _ in range(800):
+        m = bytearray(raw); pos = rng.randrange(start, len(raw) - 8); m[pos] ^= 1 << rng.randrange(8)
+        m[-8:] = _blob_hash(bytes(m[start:-8])).to_bytes(8, "little")
+        mb = np.frombuffer(bytes(m), np.uint8)
+        L.infx_session_prefetch_collect(sb, nq, _p(qa, C.c_uint16), _p(qo, C.c_uint64), 0, 0, 500)      # the importer's own (empty) slice: starts every round clean
+        if L.infx_session_prefetch_import(sb, _p(mb, C.c_uint8), C.c_int64(mb.size)) != 0:
+            refused_import += 1
+            continue
+        if L.infx_session_plan_digest(sb, nq, _p(qa, C.c_uint16), _p(qo, C.c_uint64), 500, _p(out, C.c_uint64), C.byref(used)) != 0:
+            refused_parse += 1
+        else:
+            accepted += 1
+    assert refused_import + refused_parse + accepted == 800 and refused_import + refused_parse > 0
+    # without the recomputed checksum every one of them is refused at import
+    m = bytearray(raw); m[start + 40] ^= 1
+    mb = np.frombuffer(bytes(m), np.uint8); assert L.infx_session_prefetch_import(sb, _p(mb, C.c_uint8), C.c_int64(mb.size)) != 0
+    L.infx_session_prefetch_collect(sb, nq, _p(qa, C.c_uint16), _p(qo, C.c_uint64), 0, 0, 500)
+    assert L.infx_session_prefetch_import(sb, _p(blob, C.c_uint8), C.c_int64(n)) == 0
+    assert L.infx_session_plan_digest(sb, nq, _p(qa, C.c_uint16), _p(qo, C.c_uint64), 500, _p(out, C.c_uint64), C.byref(used)) == 0 and used.value == nq
+    print("damaged plan records:", refused_import, "refused at import,", refused_parse, "at the parse,", accepted, "still well-formed")
