@@ -394,3 +394,20 @@ def test_segmented_documents_give_one_row_per_key(case):
     r = o.search(q, 10)
     assert sorted(r["keys"]) == want and len(r["keys"]) == len(want)
     assert all(s > 0 for s in r["scores"])
+
+
+def test_quirk_q18_the_lcs_of_a_second_evaluation_comes_back_from_a_byte():
+    """SearchPipeline.cs:492-503: the LCS of docIndex 0 / 1 is computed on the document's first evaluation and stored as (byte)Math.Min(lcs, 255); a document that
+    is evaluated twice (WordMatcher overlap row, then its Stage-1 row) reads the span back the second time.  For a query of more than 255 characters that the
+    document contains, the first evaluation sees the full length, the second 255 — the oracle's trace shows both (the device reproduces it: k_stage2's `split`)."""
+    words = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet", "kilo", "lima", "mike", "november", "oscar", "papa"]
+    q = " ".join(w + str(i) for i, w in enumerate(words * 3))                 # 48 words, > 255 characters
+    assert len(q) > 255
+    docs = [(0, q), (1, "alpha0 bravo1 something else"), (2, "unrelated text")]
+    o = O.OracleEngine.create_default(); o.index(docs); o.set_trace(True)
+    r = o.search(q, 10)
+    assert r["keys"][0] == 0
+    tids, tbase, tsc, tties, tfeat = o.last_trace()
+    lcs_i = O.FEAT_NAMES.index("Lcs")
+    seen = [int(tfeat[i, lcs_i]) for i in range(len(tids)) if int(tids[i]) == 0]
+    assert seen == [len(q), 255], seen                                        # first evaluation: the whole query; second: the byte
