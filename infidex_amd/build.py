@@ -9,7 +9,6 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libinfidex_hip.so")
-LIB_EXP = os.path.join(HERE, "libinfidex_hip_experiments.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off: BM25 / fusion arithmetic must round like the reference's separate fp32 mul/add (no FMA fusion)
@@ -79,12 +78,6 @@ def build(force=False, verbose=False):
     return _build(LIB, os.path.join(CSRC, "infidex_hip.o"), os.path.join(CSRC, "engine.o"), [], force, verbose)
 
 
-def build_experiments(force=False, verbose=False):
-    """libinfidex_hip_experiments.so = the product plus the alternative k_accumulate designs (stage1b/c/d.hip.inc, -DINFX_BUILD_EXPERIMENTS): loaded only by
-    the A/B parity test and the profiling scripts (INFX_LIB points the Python plumbing at it)."""
-    return _build(LIB_EXP, os.path.join(CSRC, "infidex_hip_exp.o"), os.path.join(CSRC, "engine.o"), ["-DINFX_BUILD_EXPERIMENTS"], force, verbose)
-
-
 def build_variant(tag, defines, force=False, verbose=False):
     """libinfidex_hip_<tag>.so = the product compiled with extra -D flags: A/B measurements of one kernel decision on the GPU box (INFX_LIB selects it)."""
     return _build(os.path.join(HERE, f"libinfidex_hip_{tag}.so"), os.path.join(CSRC, f"infidex_hip_{tag}.o"), os.path.join(CSRC, "engine.o"), list(defines), force, verbose)
@@ -92,8 +85,6 @@ def build_variant(tag, defines, force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
-    if "--experiments" in sys.argv:
-        print(build_experiments(force="--force" in sys.argv, verbose=True))
     for a in sys.argv[1:]:                                   # --variant=tag:-DX=1,-DY=2
         if a.startswith("--variant="):
             tag, _, defs = a[len("--variant="):].partition(":")

@@ -181,18 +181,7 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 }
 
 #include "stage1.hip.inc"
-// The measured-slower alternative designs of k_accumulate (k_accumulate2/3/4: bit-identical, 10.7 / 7.64 / 8.08 ms against 7.2 ms) are
-// experiments, not product: they are compiled only into the library tests/test_gpu_parity.py::test_accumulate_designs_agree_bit_for_bit builds
-// (-DINFX_BUILD_EXPERIMENTS, infidex_amd/build.py build_experiments) and selected there with INFX_ACC_V2 / _V3 / _V4.
-#ifdef INFX_BUILD_EXPERIMENTS
-#define ACC_SR_DEFAULT 0
-#include "stage1s.hip.inc"      // k_accumulate_sr (round 4): container-wide bitmap test + mailbox for sparse (query, container) pairs; bit-identical, not faster
-#include "stage1b.hip.inc"
-#define ACC_V3_DEFAULT 0
-#include "stage1c.hip.inc"
-#define ACC_V4_DEFAULT 0
-#include "stage1d.hip.inc"
-#endif
+#include "stage1_stream.hip.inc"   // TEMPORARY: the streaming kernel of rounds 1-5, INFX_ACC_OLD=1 (same-box A/B of round 6)
 #include "exact1.hip.inc"
 #include "exact3.hip.inc"
 #include "exactsh.hip.inc"
@@ -289,7 +278,6 @@ struct infx_stream {
     struct PendingOut { void* dst; const void* src; size_t bytes; }; std::vector<PendingOut> pendingOut; bool unsynced = false;
     std::vector<uint32_t> unionCount; std::vector<unsigned long long> unionBase{0};   // device-resident unions of the last infx_union_build
     void* dCounts = nullptr; size_t capCounts = 0;
-    void* dDense = nullptr; size_t capDense = 0; bool useSr = false;      // k_accumulate_sr -> k_accumulate hand-over flags, one byte per (query, container)
     void* dCovQ = nullptr; size_t capCovQ = 0;
     void* dCovQL = nullptr; size_t capCovQL = 0; uint32_t nLongQ = 0;      // infx_stage2_long_queries: the long-query table of the next Stage-2 call
     void* dCovC = nullptr; size_t capCovC = 0;
@@ -499,124 +487,50 @@ static Arena make_arena(infx_stream* s) {
     return Arena{s->arDoc, s->arScore, s->arCls, s->arMask, s->arExc, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
                  (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes, (uint32_t*)((unsigned long long*)s->dQBytes + s->lastNqAlloc), (uint2*)s->dDir, s->maskWords};
 }
-static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX_ACC_STRIPE"); int x = e ? atoi(e) : 0; return (x >= 1 && x <= 64) ? x : 4; }(); return v; }
-// LDS8 (stage1.hip.inc) addresses the tf array by raw LDS offset: true only while k_accumulate owns no static __shared__ data, i.e. its dynamic
-// LDS starts at address 0.  Checked once per instantiation against the code object; a violation fails the search loudly.
-template <int R> static bool acc_lds_layout_ok() {
-    static const bool ok = [] {
-        hipFuncAttributes a1{}, a2{};
-        if (hipFuncGetAttributes(&a1, (const void*)k_accumulate<R, 1>) != hipSuccess || hipFuncGetAttributes(&a2, (const void*)k_accumulate<R, 2>) != hipSuccess) return false;
-        return a1.sharedSizeBytes == 0 && a2.sharedSizeBytes == 0;
-    }();
-    return ok;
-}
-#ifdef INFX_BUILD_EXPERIMENTS
-template <int R, int MW, int CAP> static bool acc2_launch(infx_stream* s, uint32_t nq, Arena ar, int useGrp) {
-    static const bool ok = [] { hipFuncAttributes a{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate2<R, MW, CAP>) == hipSuccess && a.sharedSizeBytes == 0; }();
-    if (!ok) return false;                                   // LDS8 / LDS32 address the dynamic block from LDS address 0: no static __shared__ allowed
-    const int stripe = acc_stripe();
-    static const int dbg = [] { const char* e = getenv("INFX_ACC_DBG"); return e ? atoi(e) : 0; }();      // kernel ablation for profiling only (results are then meaningless)
-    const size_t offBits = ((size_t)R + 64 + (size_t)(CAP + 1) * (MW * 8) + (size_t)(CAP + 1) * 4 + 15) & ~(size_t)15;
-    const size_t lds = offBits + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + CAP * 2;
-    const uint64_t blocks = (uint64_t)nq * ((s->ix->d.nRanges + stripe - 1) / stripe);
-    k_accumulate2<R, MW, CAP><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
-                                                                                (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, dbg);
-    return true;
-}
-// k_accumulate2 (stage1b.hip.inc, the "mask scatter" design) is a measured alternative, bit-identical to k_accumulate but slower on the 10 M-doc batch
-// (10.7 vs 7.5 ms, profiles/r03_accumulate2.md): it runs only with INFX_ACC_V2=1 (A/B parity test, profiling) and for batches of <= 64-term queries
-static bool acc_v1_forced() { static const bool v = [] { const char* e = getenv("INFX_ACC_V2"); return !(e && e[0] == '1'); }(); return v; }
-// k_accumulate3 (stage1c.hip.inc, "probe, pool, score"): same LDS layout as k_accumulate.  INFX_ACC_V3=0 falls back to k_accumulate (A/B test, profiling).
-static bool acc_v3_enabled() { static const bool v = [] { const char* e = getenv("INFX_ACC_V3"); return ACC_V3_DEFAULT ? !(e && e[0] == '0') : (e && e[0] == '1'); }(); return v; }
-template <int R, int MW> static bool acc3_launch(infx_stream* s, uint32_t nq, Arena ar, int useGrp) {
-    static const bool ok = [] { hipFuncAttributes a{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate3<R, MW>) == hipSuccess && a.sharedSizeBytes == 0; }();
-    if (!ok) return false;                                   // LDS8 addresses the dynamic block from LDS address 0: no static __shared__ allowed
-    const int stripe = acc_stripe();
-    static const int dbg = [] { const char* e = getenv("INFX_ACC_DBG"); return e ? atoi(e) : 0; }();      // kernel ablation for profiling only (results are then meaningless)
-    const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
-    const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
-    k_accumulate3<R, MW><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
-                                                                            (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, dbg);
-    return true;
-}
-static int acc2_cap() { static const int v = [] { const char* e = getenv("INFX_ACC2_CAP"); const int x = e ? atoi(e) : 0; return x == 64 ? 64 : 128; }(); return v; }
-// k_accumulate4 (stage1d.hip.inc): 4-bit tf cells, passes of SUP x R documents.  INFX_ACC_V4 = 1 / 0 overrides the default; INFX_ACC_SUP = 2 (default) or 4.
-static bool acc_v4_enabled() { static const bool v = [] { const char* e = getenv("INFX_ACC_V4"); return ACC_V4_DEFAULT ? !(e && e[0] == '0') : (e && e[0] == '1'); }(); return v; }
-static int acc_sup() { static const int v = [] { const char* e = getenv("INFX_ACC_SUP"); return (e && atoi(e) == 4) ? 4 : 2; }(); return v; }
-template <int R, int MW, int SUP> static bool acc4_launch(infx_stream* s, uint32_t nq, Arena ar, int useGrp) {
-    static const bool ok = [] { hipFuncAttributes a{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate4<R, MW, SUP>) == hipSuccess && a.sharedSizeBytes == 0; }();
-    if (!ok) return false;                                   // LDS32 addresses the dynamic block from LDS address 0: no static __shared__ allowed
-    static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
-    const int stripe = std::max(SUP, (acc_stripe() / SUP) * SUP);                   // whole passes per block
-    constexpr size_t SR = (size_t)R * SUP;
-    const size_t lds = SR / 2 + 272 + (SR / 32 + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
-    const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);
-    k_accumulate4<R, MW, SUP><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
-                                                                                 (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, dbgSkip);
-    return true;
-}
-// passes of SUP x R documents must divide a 65 536-id container, keep a slice within 16 bits of postings, and leave the packed sentinel id (0xFFFFFF)
-// outside the last pass
-template <int R, int SUP> static bool acc4_fits(const infx_index* ix) {
-    return (size_t)R * SUP <= 32768 && (65536 % ((size_t)R * SUP)) == 0 && (!ix->d.packed || (uint64_t)ix->d.N + (uint64_t)R * SUP + 512 < (1ull << 24));
-}
-#endif
+static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX_ACC_STRIPE"); int x = e ? atoi(e) : 0; return (x == 1 || x == 2 || x == 8 || x == 16) ? x : 4; }(); return v; }      // a power of two
+// stripe: consecutive doc ranges one wave of k_accumulate takes (candidate bitmap of stripe * R bits in LDS; stripe-local doc ids are 16 bits)
+template <int R> static int acc_stripe_for() { return std::max(1, std::min(acc_stripe(), 65536 / R)); }      // (R is a power of two: so is the result)
+static int acc_ch() { static const int v = [] { const char* e = getenv("INFX_ACC_CH"); const int x = e ? atoi(e) : 0; return (x == 256 || x == 512 || x == 2048) ? x : 1024; }(); return v; }      // postings per LDS stage
+static bool acc_old() { static const bool v = [] { const char* e = getenv("INFX_ACC_OLD"); return e && e[0] == '1'; }(); return v; }
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp, int maxRef) {
-#ifdef INFX_BUILD_EXPERIMENTS
-    if (acc_v4_enabled() && acc_v1_forced() && !acc_v3_enabled()) {
-        const int mw = ar.maskWords == 2 ? 2 : 1;
-        bool done = false, ok = true;
-        if (acc_sup() == 4 && acc4_fits<R, 4>(s->ix)) { ok = mw == 2 ? acc4_launch<R, 2, 4>(s, nq, ar, useGrp) : acc4_launch<R, 1, 4>(s, nq, ar, useGrp); done = true; }
-        else if (acc4_fits<R, 2>(s->ix)) { ok = mw == 2 ? acc4_launch<R, 2, 2>(s, nq, ar, useGrp) : acc4_launch<R, 1, 2>(s, nq, ar, useGrp); done = true; }
-        if (done) { if (!ok) s->accLayoutBad = true; return; }
-    }
-    if (maxRef <= 64 && acc_v3_enabled() && acc_v1_forced()) {
-        if (!(maxRef <= 32 ? acc3_launch<R, 1>(s, nq, ar, useGrp) : acc3_launch<R, 2>(s, nq, ar, useGrp))) s->accLayoutBad = true;
-        return;
-    }
-    if (maxRef <= 64 && !acc_v1_forced()) {
-        bool ok;
-        if (acc2_cap() == 64) ok = maxRef <= 32 ? acc2_launch<R, 1, 64>(s, nq, ar, useGrp) : acc2_launch<R, 2, 64>(s, nq, ar, useGrp);
-        else ok = maxRef <= 32 ? acc2_launch<R, 1, 128>(s, nq, ar, useGrp) : acc2_launch<R, 2, 128>(s, nq, ar, useGrp);
-        if (!ok) s->accLayoutBad = true;
-        return;
-    }
-#else
     (void)maxRef;
-#endif
-    if (!acc_lds_layout_ok<R>()) { s->accLayoutBad = true; return; }
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
-    const int stripe = acc_stripe();
-    const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
-    const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
-    // sparse (query, container) pairs first (k_accumulate_sr raises dDense for the pairs it leaves to k_accumulate); needs packed postings and stripes inside one container
-    const uint8_t* dense = nullptr; int nSuper = 0;
-#ifdef INFX_BUILD_EXPERIMENTS
-    if (s->useSr && s->dDense && s->ix->d.packed && (65536 / R) % stripe == 0) {
-        constexpr int RPC = 65536 / R;
-        nSuper = (s->ix->d.nRanges + RPC - 1) / RPC;
-        const size_t ldsS = (size_t)(SRA_WORDS + 2) * 6 + SRA_CAP + 64 + INFX_NCLASS * 4 + SRA_CAP * 2 + (size_t)RPC * 4 + 16;
-        const uint64_t blocksS = (uint64_t)nq * 8u * ((nSuper + 7) / 8);
-        static const bool okS = [] { hipFuncAttributes a{}, b2{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate_sr<R, 1>) == hipSuccess && a.sharedSizeBytes == 0 &&
-                                                                      hipFuncGetAttributes(&b2, (const void*)k_accumulate_sr<R, 2>) == hipSuccess && b2.sharedSizeBytes == 0; }();
-        if (okS && blocksS <= 0x7FFFFFFFull) {
-            hipMemsetAsync(s->dDense, 0, (size_t)nq * nSuper, s->st);
-            if (ar.maskWords == 2)
-                k_accumulate_sr<R, 2><<<dim3((unsigned)blocksS), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, (uint8_t*)s->dDense, nSuper, dbgSkip);
-            else
-                k_accumulate_sr<R, 1><<<dim3((unsigned)blocksS), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, (uint8_t*)s->dDense, nSuper, dbgSkip);
-            dense = (const uint8_t*)s->dDense;
-        }
+    if (acc_old()) {                                             // TEMPORARY A/B partner (stage1_stream.hip.inc)
+        hipFuncAttributes a1{}, a2{};
+        if (hipFuncGetAttributes(&a1, (const void*)k_accumulate_stream<R, 1>) != hipSuccess || hipFuncGetAttributes(&a2, (const void*)k_accumulate_stream<R, 2>) != hipSuccess || a1.sharedSizeBytes || a2.sharedSizeBytes) { s->accLayoutBad = true; return; }
+        const int stripe = 4;
+        const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
+        const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);
+        if (ar.maskWords == 2)
+            k_accumulate_stream<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
+                                                                               (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, nullptr, 0);
+        else
+            k_accumulate_stream<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
+                                                                               (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, nullptr, 0);
+        return;
     }
-#endif
-    if (ar.maskWords == 2)
-        k_accumulate<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nSuper);
-    else
-        k_accumulate<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nSuper);
-    if (dbgSkip & 8) { unsigned long long h[4] = {0, 0, 0, 0}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 32, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 32);
-        fprintf(stderr, "[infx] k_accumulate stats: %llu blocks with candidates of %llu, %.2f rounds/block, %.1f candidates/block\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0); }
+    (void)maxT;
+    {   // LDS32 (stage1.hip.inc) addresses the posting stage by raw LDS offset: true only while k_accumulate owns no static __shared__ data
+        static const bool ok = [] { hipFuncAttributes a{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate<R, 1, 1024>) == hipSuccess && a.sharedSizeBytes == 0; }();
+        if (!ok) { s->accLayoutBad = true; return; }
+    }
+    const int stripe = acc_stripe_for<R>();
+    const int ch = acc_ch();
+    const size_t sw = (size_t)stripe * (R / 32);
+    const size_t lds = (size_t)ch * 4 + (sw + 64 + 4) * 4 + INFX_NCLASS * 4 + ACC_CAP * 2;      // stage | padded bitmap (one pad word per lane) | class histogram | slot table
+    const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
+#define ACC_LAUNCH(MW_, CH_) k_accumulate<R, MW_, CH_><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, \
+        (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats)
+    switch (ch) {
+        case 256: if (ar.maskWords == 2) ACC_LAUNCH(2, 256); else ACC_LAUNCH(1, 256); break;
+        case 512: if (ar.maskWords == 2) ACC_LAUNCH(2, 512); else ACC_LAUNCH(1, 512); break;
+        case 2048: if (ar.maskWords == 2) ACC_LAUNCH(2, 2048); else ACC_LAUNCH(1, 2048); break;
+        default: if (ar.maskWords == 2) ACC_LAUNCH(2, 1024); else ACC_LAUNCH(1, 1024); break;
+    }
+#undef ACC_LAUNCH
+    if (dbgSkip & 8) { unsigned long long h[12] = {}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 96, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 96);
+        fprintf(stderr, "[infx] k_accumulate stripes by candidates <=64 / <=256 / <=1024 / more: %llu %llu %llu %llu, their candidates: %llu %llu %llu %llu\n", h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+        fprintf(stderr, "[infx] k_accumulate stats: %llu stripes with candidates of %llu, %.2f rounds/stripe, %.1f candidates/stripe, %llu chunks staged (%.1f per round)\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0, h[3], h[1] ? (double)h[3] / h[1] : 0.0); }
 }
 
 // Longest-queries-first order for k_select's workgroups (k_select_order, stage1.hip.inc); nullptr: query order (batches beyond SEL_ORDER_MAX, INFX_SELECT_LPT=0)
@@ -1089,7 +1003,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     for (auto e : ev) HIPCHK(hipEventCreate(e));
     HIPCHK(hipEventCreateWithFlags(&s->evSync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
-    HIPCHK(hipMalloc((void**)&s->dStats, 64)); HIPCHK(hipMemset(s->dStats, 0, 64));
+    HIPCHK(hipMalloc((void**)&s->dStats, 128)); HIPCHK(hipMemset(s->dStats, 0, 128));
     HIPCHK(hipMalloc((void**)&s->dExactStat, 32)); HIPCHK(hipMemset(s->dExactStat, 0, 32));      // [0..3] replay outcome counters, [4..7] k_select flag reasons
     HIPCHK(hipMalloc((void**)&s->exCounters, 32)); HIPCHK(hipMemset(s->exCounters, 0, 32));
     *out = s; return INFX_OK;
@@ -1100,7 +1014,7 @@ void infx_stream_destroy(infx_stream* s) {
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
                   s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters, s->exContEnd, s->dExProf, s->dSelOrder,
-                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount, s->dDense};
+                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
     for (void* p : s->parked) hipFree(p);
@@ -1257,16 +1171,6 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     GROW(s->dBlockOutHi, s->capBlockOutHi, (size_t)nq * 4);        // qCursor
     GROW(s->dQBytes, s->capQBytes, (size_t)nq * 12); s->lastNqAlloc = nq;      // per query: algorithmic bytes (u64) | best emitted score bits (u32, behind the nq u64s)
     GROW(s->dCounts, s->capCounts, (size_t)nq * INFX_NCLASS * 4);
-    {   // k_accumulate_sr's per-(query, container) hand-over flags (INFX_ACC_SR=0: everything through k_accumulate)
-#ifdef INFX_BUILD_EXPERIMENTS
-        static const bool sr = [] { const char* e = getenv("INFX_ACC_SR"); return ACC_SR_DEFAULT ? !(e && e[0] == '0') : (e && e[0] == '1'); }();
-#else
-        static const bool sr = false;
-#endif
-        if (sr) GROW(s->dDense, s->capDense, (size_t)nq * ((size_t)ix->d.nRanges + 1)); else { s->dDense = s->capDense ? s->dDense : nullptr; if (!s->capDense) s->dDense = nullptr; }
-        if (!sr && s->dDense) { /* switched off at run time: keep the buffer, do not use it */ }
-        s->useSr = sr;
-    }
     for (size_t i = 0; i < dt.size(); i++) if (termOfEntry[i] >= 0) dt[i].skip = ix->hSkipIdx[termOfEntry[i]];
 
     UP(s->dQueries, dq.data(), nq * sizeof(DevQuery));
@@ -1290,7 +1194,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
         case 8192: launch_acc<8192>(s, nq, ar, maxT, useGrp, maxRef); break;
         default: launch_acc<16384>(s, nq, ar, maxT, useGrp, maxRef); break;
     }
-    if (s->accLayoutBad) return fail(INFX_EHIP, "k_accumulate was built with static LDS: its byte addressing (LDS8) is invalid%s");
+    if (s->accLayoutBad) return fail(INFX_EHIP, "k_accumulate was built with static LDS: its raw LDS addressing (LDS32) is invalid%s");
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evA1, s->st));
     s->timedAcc = true;

@@ -515,8 +515,10 @@ def test_high_term_frequencies():
 
 
 def test_accumulate_designs_agree_bit_for_bit(tmp_path):
-    """k_accumulate (tf scatter + probe), k_accumulate2 (mask scatter), k_accumulate3 (probe, pool, score) and k_accumulate4 (4-bit cells, wider passes) are the same
-    arithmetic in the same order: final rows, fp32 scores and the Stage-1 rows (ids and score bits) of a fuzzy batch must be identical, with deletions too."""
+    """k_accumulate is the same arithmetic in the same order whatever its schedule: posting stages of 256 .. 2048 postings (INFX_ACC_CH: slices cross the stage in more or fewer chunks), stripes of 1 / 4 / 8
+    doc ranges per wave (the candidates of a round then come from one or several ranges), and — while it is still in the tree — the streaming kernel of rounds
+    1-5 (byte scatter + probe per (list, range) visit, INFX_ACC_OLD=1).  Final rows, fp32 scores and the Stage-1 rows (ids and score bits) of a fuzzy batch must
+    be identical, with deletions too."""
     import os
     import subprocess
     import sys
@@ -540,19 +542,12 @@ for tag in ("plain", "deleted"):
 np.savez(sys.argv[1], **out)
 '''
     res = []
-    from infidex_amd import build as _build
-    exp_lib = _build.build_experiments()
-    variants = [dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate
-                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0", INFX_ACC_SKIP="32"),  # ... with the query-fastest block map
-                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0", INFX_ACC_SR="1"),     # k_accumulate_sr for the sparse containers + k_accumulate for the rest
-                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="0", INFX_ACC_SR="0"),     # ... switched off
-                dict(INFX_ACC_V2="1", INFX_ACC_V3="0", INFX_ACC_V4="0"),                      # k_accumulate2
-                dict(INFX_ACC_V2="0", INFX_ACC_V3="1", INFX_ACC_V4="0"),                      # k_accumulate3
-                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="1", INFX_ACC_SUP="2"),    # k_accumulate4, passes of 2 ranges
-                dict(INFX_ACC_V2="0", INFX_ACC_V3="0", INFX_ACC_V4="1", INFX_ACC_SUP="4")]    # ... of 4 ranges
+    variants = [dict(),                                             # shipping schedule
+                dict(INFX_ACC_CH="256"), dict(INFX_ACC_CH="512"),     # smaller posting stages (more chunks per slice)
+                dict(INFX_ACC_STRIPE="1"), dict(INFX_ACC_STRIPE="8"), dict(INFX_ACC_STRIPE="2", INFX_ACC_CH="2048"),
+                dict(INFX_ACC_OLD="1")]                             # the streaming kernel (temporary A/B partner)
     for vi, var in enumerate(variants):
         env = dict(os.environ); env.update(var)
-        env["INFX_LIB"] = exp_lib                     # the alternative designs are not part of the product library (-DINFX_BUILD_EXPERIMENTS)
         env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         out = str(tmp_path / f"acc{vi}.npz")
         subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=900)
