@@ -181,7 +181,6 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 }
 
 #include "stage1.hip.inc"
-#include "stage1_stream.hip.inc"   // TEMPORARY: the streaming kernel of rounds 1-5, INFX_ACC_OLD=1 (same-box A/B of round 6)
 #include "exact1.hip.inc"
 #include "exact3.hip.inc"
 #include "exactsh.hip.inc"
@@ -487,50 +486,32 @@ static Arena make_arena(infx_stream* s) {
     return Arena{s->arDoc, s->arScore, s->arCls, s->arMask, s->arExc, (const unsigned long long*)s->dBlockOut, (uint32_t*)s->dBlockOutHi,
                  (uint32_t*)s->dCounts, s->dOverflow, (unsigned long long*)s->dQBytes, (uint32_t*)((unsigned long long*)s->dQBytes + s->lastNqAlloc), (uint2*)s->dDir, s->maskWords};
 }
-static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX_ACC_STRIPE"); int x = e ? atoi(e) : 0; return (x == 1 || x == 2 || x == 8 || x == 16) ? x : 4; }(); return v; }      // a power of two
-// stripe: consecutive doc ranges one wave of k_accumulate takes (candidate bitmap of stripe * R bits in LDS; stripe-local doc ids are 16 bits)
-template <int R> static int acc_stripe_for() { return std::max(1, std::min(acc_stripe(), 65536 / R)); }      // (R is a power of two: so is the result)
-static int acc_ch() { static const int v = [] { const char* e = getenv("INFX_ACC_CH"); const int x = e ? atoi(e) : 0; return (x == 256 || x == 512 || x == 2048) ? x : 1024; }(); return v; }      // postings per LDS stage
-static bool acc_old() { static const bool v = [] { const char* e = getenv("INFX_ACC_OLD"); return e && e[0] == '1'; }(); return v; }
+static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX_ACC_STRIPE"); int x = e ? atoi(e) : 0; return (x >= 1 && x <= 64) ? x : 4; }(); return v; }
+// LDS8 (stage1.hip.inc) addresses the tf array by raw LDS offset: true only while k_accumulate owns no static __shared__ data, i.e. its dynamic
+// LDS starts at address 0.  Checked once per instantiation against the code object; a violation fails the search loudly.
+template <int R> static bool acc_lds_layout_ok() {
+    static const bool ok = [] {
+        hipFuncAttributes a1{}, a2{};
+        if (hipFuncGetAttributes(&a1, (const void*)k_accumulate<R, 1>) != hipSuccess || hipFuncGetAttributes(&a2, (const void*)k_accumulate<R, 2>) != hipSuccess) return false;
+        return a1.sharedSizeBytes == 0 && a2.sharedSizeBytes == 0;
+    }();
+    return ok;
+}
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp, int maxRef) {
     (void)maxRef;
+    if (!acc_lds_layout_ok<R>()) { s->accLayoutBad = true; return; }
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
-    if (acc_old()) {                                             // TEMPORARY A/B partner (stage1_stream.hip.inc)
-        hipFuncAttributes a1{}, a2{};
-        if (hipFuncGetAttributes(&a1, (const void*)k_accumulate_stream<R, 1>) != hipSuccess || hipFuncGetAttributes(&a2, (const void*)k_accumulate_stream<R, 2>) != hipSuccess || a1.sharedSizeBytes || a2.sharedSizeBytes) { s->accLayoutBad = true; return; }
-        const int stripe = 4;
-        const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
-        const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);
-        if (ar.maskWords == 2)
-            k_accumulate_stream<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                               (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, nullptr, 0);
-        else
-            k_accumulate_stream<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                               (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, nullptr, 0);
-        return;
-    }
-    (void)maxT;
-    {   // LDS32 (stage1.hip.inc) addresses the posting stage by raw LDS offset: true only while k_accumulate owns no static __shared__ data
-        static const bool ok = [] { hipFuncAttributes a{}; return hipFuncGetAttributes(&a, (const void*)k_accumulate<R, 1, 1024>) == hipSuccess && a.sharedSizeBytes == 0; }();
-        if (!ok) { s->accLayoutBad = true; return; }
-    }
-    const int stripe = acc_stripe_for<R>();
-    const int ch = acc_ch();
-    const size_t sw = (size_t)stripe * (R / 32);
-    const size_t lds = (size_t)ch * 4 + (sw + 64 + 4) * 4 + INFX_NCLASS * 4 + ACC_CAP * 2;      // stage | padded bitmap (one pad word per lane) | class histogram | slot table
+    const int stripe = acc_stripe();
+    const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
     const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
-#define ACC_LAUNCH(MW_, CH_) k_accumulate<R, MW_, CH_><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, \
-        (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats)
-    switch (ch) {
-        case 256: if (ar.maskWords == 2) ACC_LAUNCH(2, 256); else ACC_LAUNCH(1, 256); break;
-        case 512: if (ar.maskWords == 2) ACC_LAUNCH(2, 512); else ACC_LAUNCH(1, 512); break;
-        case 2048: if (ar.maskWords == 2) ACC_LAUNCH(2, 2048); else ACC_LAUNCH(1, 2048); break;
-        default: if (ar.maskWords == 2) ACC_LAUNCH(2, 1024); else ACC_LAUNCH(1, 1024); break;
-    }
-#undef ACC_LAUNCH
-    if (dbgSkip & 8) { unsigned long long h[12] = {}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 96, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 96);
-        fprintf(stderr, "[infx] k_accumulate stripes by candidates <=64 / <=256 / <=1024 / more: %llu %llu %llu %llu, their candidates: %llu %llu %llu %llu\n", h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
-        fprintf(stderr, "[infx] k_accumulate stats: %llu stripes with candidates of %llu, %.2f rounds/stripe, %.1f candidates/stripe, %llu chunks staged (%.1f per round)\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0, h[3], h[1] ? (double)h[3] / h[1] : 0.0); }
+    if (ar.maskWords == 2)
+        k_accumulate<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats);
+    else
+        k_accumulate<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats);
+    if (dbgSkip & 8) { unsigned long long h[4] = {0, 0, 0, 0}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 32, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 32);
+        fprintf(stderr, "[infx] k_accumulate stats: %llu ranges with candidates (%llu blocks), %.2f rounds/range, %.1f candidates/range\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0); }
 }
 
 // Longest-queries-first order for k_select's workgroups (k_select_order, stage1.hip.inc); nullptr: query order (batches beyond SEL_ORDER_MAX, INFX_SELECT_LPT=0)
@@ -1003,7 +984,7 @@ int32_t infx_stream_create(infx_index* ix, infx_stream** out) {
     for (auto e : ev) HIPCHK(hipEventCreate(e));
     HIPCHK(hipEventCreateWithFlags(&s->evSync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&s->dCursor, 16)); HIPCHK(hipMalloc((void**)&s->dOverflow, 4));
-    HIPCHK(hipMalloc((void**)&s->dStats, 128)); HIPCHK(hipMemset(s->dStats, 0, 128));
+    HIPCHK(hipMalloc((void**)&s->dStats, 64)); HIPCHK(hipMemset(s->dStats, 0, 64));
     HIPCHK(hipMalloc((void**)&s->dExactStat, 32)); HIPCHK(hipMemset(s->dExactStat, 0, 32));      // [0..3] replay outcome counters, [4..7] k_select flag reasons
     HIPCHK(hipMalloc((void**)&s->exCounters, 32)); HIPCHK(hipMemset(s->exCounters, 0, 32));
     *out = s; return INFX_OK;
@@ -1194,7 +1175,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
         case 8192: launch_acc<8192>(s, nq, ar, maxT, useGrp, maxRef); break;
         default: launch_acc<16384>(s, nq, ar, maxT, useGrp, maxRef); break;
     }
-    if (s->accLayoutBad) return fail(INFX_EHIP, "k_accumulate was built with static LDS: its raw LDS addressing (LDS32) is invalid%s");
+    if (s->accLayoutBad) return fail(INFX_EHIP, "k_accumulate was built with static LDS: its byte addressing (LDS8) is invalid%s");
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evA1, s->st));
     s->timedAcc = true;

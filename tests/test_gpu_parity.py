@@ -514,11 +514,11 @@ def test_high_term_frequencies():
     assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0 and st["s1_boundary"] == 0, st
 
 
-def test_accumulate_designs_agree_bit_for_bit(tmp_path):
-    """k_accumulate is the same arithmetic in the same order whatever its schedule: posting stages of 256 .. 2048 postings (INFX_ACC_CH: slices cross the stage in more or fewer chunks), stripes of 1 / 4 / 8
-    doc ranges per wave (the candidates of a round then come from one or several ranges), and — while it is still in the tree — the streaming kernel of rounds
-    1-5 (byte scatter + probe per (list, range) visit, INFX_ACC_OLD=1).  Final rows, fp32 scores and the Stage-1 rows (ids and score bits) of a fuzzy batch must
-    be identical, with deletions too."""
+def test_accumulate_schedules_agree_bit_for_bit(tmp_path):
+    """k_accumulate is the same arithmetic in the same order however its (query, stripe) blocks are scheduled: the XCD-aware block map or the query-fastest one
+    (INFX_ACC_SKIP=32), stripes of 1 / 2 / 8 doc ranges per wave.  Final rows, fp32 scores and the Stage-1 rows (ids and score bits) of a fuzzy batch must be
+    identical, with deletions too.  (Until round 6 this test also held the alternative accumulation designs — mask scatter, probe-pool-score, 4-bit cells,
+    container mailbox, and round 6's search kernel; all bit-identical, none faster, all deleted: HISTORY.md.)"""
     import os
     import subprocess
     import sys
@@ -542,10 +542,7 @@ for tag in ("plain", "deleted"):
 np.savez(sys.argv[1], **out)
 '''
     res = []
-    variants = [dict(),                                             # shipping schedule
-                dict(INFX_ACC_CH="256"), dict(INFX_ACC_CH="512"),     # smaller posting stages (more chunks per slice)
-                dict(INFX_ACC_STRIPE="1"), dict(INFX_ACC_STRIPE="8"), dict(INFX_ACC_STRIPE="2", INFX_ACC_CH="2048"),
-                dict(INFX_ACC_OLD="1")]                             # the streaming kernel (temporary A/B partner)
+    variants = [dict(), dict(INFX_ACC_SKIP="32"), dict(INFX_ACC_STRIPE="1"), dict(INFX_ACC_STRIPE="2"), dict(INFX_ACC_STRIPE="8")]
     for vi, var in enumerate(variants):
         env = dict(os.environ); env.update(var)
         env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
