@@ -272,45 +272,38 @@ struct DocSource {   // n docs, fieldCount fields each; offs has n*fieldCount+1 
 // ordinal order.  The segments cover [0, flushed) without gaps, in order (what a sequence of Flush calls leaves: VectorModel.cs:804-815); the documents
 // behind them are the live tail.
 struct SegmentPostings { int32_t docBase = 0, docCount = 0; const std::vector<ustr>* terms = nullptr; const std::vector<uint64_t>* off = nullptr; const std::vector<int32_t>* doc = nullptr; const std::vector<uint8_t>* w = nullptr; };
-// ix.terms holds every term of the corpus (ids in first-appearance order: the documents were tokenised) but only the live tail's postings; the segments'
-// postings are put in front of them, list by list.  What a segment cannot give back: the reference's df counter counts a document twice when a term's weight
-// byte saturates inside it (Term.cs:118-146, quirk Q5) and drops the lists of stop terms — a segment stores neither, so df here is the number of postings.
+// ix.terms is the index accumulated from ALL documents (so the df counter's double counts on saturated weight bytes — Term.cs:118-146, quirk Q5 — and the
+// stop-term decisions are those of an unflushed index: a segment stores neither, and its writer drops the lists of terms that were stop terms at flush time).
+// The segments' postings then REPLACE the accumulated (document, weight) pairs of their document ranges, list by list: a list of a segment must hold exactly the
+// documents the accumulation found for that term in the segment's range (else the segment was written from other documents); a term without a list in a segment
+// keeps its accumulated postings (a stop term at flush time stays one: its postings are dropped with the others after the df pass).  Round 5 accumulated only the
+// live tail and spliced the segment lists in front: df and stop state of the flushed range were then the posting counts.
 inline const char* splice_segments(HostIndex& ix, const std::vector<SegmentPostings>& segs, int threads) {
-    Csr& C = ix.terms; const size_t T = C.K();
-    std::vector<std::vector<uint32_t>> idOf(segs.size());
+    Csr& C = ix.terms;
     std::atomic<int> bad{0};
     for (size_t s = 0; s < segs.size(); s++) {
-        const auto& names = *segs[s].terms; idOf[s].resize(names.size());
+        const auto& names = *segs[s].terms; const auto& o = *segs[s].off; const auto& d = *segs[s].doc; const auto& w = *segs[s].w;
+        const int32_t base = segs[s].docBase, cnt = segs[s].docCount;
         parallel_for((int64_t)names.size(), threads, [&](int64_t b, int64_t e, int) {
-            for (int64_t t = b; t < e; t++) { const int64_t id = C.keys.find(uview(names[t].data(), names[t].size())); if (id < 0) bad.store(1); else idOf[s][t] = (uint32_t)id; }
+            for (int64_t t = b; t < e; t++) {
+                const int64_t id = C.keys.find(uview(names[t].data(), names[t].size()));
+                if (id < 0) { bad.store(1); continue; }
+                const int32_t* lo = C.doc.data() + C.off[id]; const int32_t* hi = C.doc.data() + C.off[id + 1];
+                const int32_t* a = std::lower_bound(lo, hi, base); const int32_t* z = std::lower_bound(a, hi, base + cnt);
+                if ((uint64_t)(z - a) != o[t + 1] - o[t]) { bad.store(2); continue; }
+                uint64_t p = (uint64_t)(a - C.doc.data());
+                for (uint64_t i = o[t]; i < o[t + 1]; i++, p++) { if (d[i] < 0 || d[i] >= cnt || d[i] + base != C.doc[p]) { bad.store(2); break; } C.w[p] = w[i]; }
+            }
         });
-        if (bad.load()) return "a segment holds a term the documents do not produce: it was written from other documents";
+        if (bad.load() == 1) return "a segment holds a term the documents do not produce: it was written from other documents";
+        if (bad.load()) return "a segment list does not hold the documents the supplied documents produce for its term: it was written from other documents";
     }
-    std::vector<uint64_t> noff(T + 1, 0);
-    for (size_t k = 0; k < T; k++) noff[k + 1] = C.len((uint32_t)k);
-    for (size_t s = 0; s < segs.size(); s++) { const auto& o = *segs[s].off; for (size_t t = 0; t < idOf[s].size(); t++) noff[idOf[s][t] + 1] += o[t + 1] - o[t]; }
-    for (size_t k = 0; k < T; k++) noff[k + 1] += noff[k];
-    std::vector<uint64_t> cursor(noff.begin(), noff.end() - 1);
-    std::vector<std::vector<uint64_t>> start(segs.size());
-    for (size_t s = 0; s < segs.size(); s++) { const auto& o = *segs[s].off; start[s].resize(idOf[s].size()); for (size_t t = 0; t < idOf[s].size(); t++) { start[s][t] = cursor[idOf[s][t]]; cursor[idOf[s][t]] += o[t + 1] - o[t]; } }
-    std::vector<int32_t> nd(noff[T]); std::vector<uint8_t> nw(noff[T]); std::vector<uint16_t> nm(noff[T], 0);
-    parallel_for((int64_t)T, threads, [&](int64_t b, int64_t e, int) {           // the live tail behind the segments' postings
-        for (int64_t k = b; k < e; k++) { const uint64_t n = C.len((uint32_t)k), a = C.off[k], z = cursor[k]; for (uint64_t i = 0; i < n; i++) { nd[z + i] = C.doc[a + i]; nw[z + i] = C.w[a + i]; nm[z + i] = C.meta[a + i]; } }
-    });
-    for (size_t s = 0; s < segs.size(); s++) {
-        const auto& o = *segs[s].off; const auto& d = *segs[s].doc; const auto& w = *segs[s].w; const int32_t base = segs[s].docBase, cnt = segs[s].docCount;
-        parallel_for((int64_t)idOf[s].size(), threads, [&](int64_t b, int64_t e, int) {
-            for (int64_t t = b; t < e; t++) for (uint64_t i = o[t], z = start[s][t]; i < o[t + 1]; i++, z++) { if (d[i] < 0 || d[i] >= cnt) { bad.store(1); continue; } nd[z] = d[i] + base; nw[z] = w[i]; }
-        });
-        if (bad.load()) return "a segment posting lies outside the segment's document range";
-    }
-    C.off.swap(noff); C.doc.swap(nd); C.w.swap(nw); C.meta.swap(nm);
     return nullptr;
 }
 
 inline const char* build_index(const DocSource& src, HostIndex& ix, const std::vector<SegmentPostings>* segs = nullptr) {
     const HostConfig& cfg = ix.cfg;
-    int64_t flushed = 0;                                     // documents [0, flushed): postings from segments, not accumulated here
+    int64_t flushed = 0;                                     // documents [0, flushed): their postings are replaced by the segments' (splice_segments)
     if (segs) for (auto& g : *segs) { if (g.docBase != flushed || g.docCount < 0) return "segments must cover the documents from 0 without gaps, in order"; flushed += g.docCount; }
     if (flushed > src.n) return "the segments hold more documents than were supplied";
     int threads = cfg.threads > 0 ? cfg.threads : effective_cpus();
@@ -387,7 +380,7 @@ inline const char* build_index(const DocSource& src, HostIndex& ix, const std::v
                         if (nw <= 255.f) wgt = (uint8_t)std::nearbyint((double)nw); else ovf++;
                     }
                     int net = 1 + ovf;
-                    if (d >= flushed) M.add(lid, (int32_t)d, wgt, (uint16_t)((std::min(net - 1, 255) << 8) | std::min(maxT - 1, 255)));
+                    M.add(lid, (int32_t)d, wgt, (uint16_t)((std::min(net - 1, 255) << 8) | std::min(maxT - 1, 255)));
                     i = j;
                 }
                 // prefix index over indexText tokens (VectorModel.cs:109)

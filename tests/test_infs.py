@@ -196,9 +196,9 @@ def _flush_like(o, tmp_path, cuts):
 
 
 def test_an_engine_populated_from_segments_holds_the_index_of_the_documents(tmp_path):
-    """Two flushed segments + a live tail -> infx_engine_index_from_segments: the flushed ranges' postings come from the files (only the tail's are accumulated
-    from the texts) and the host index is, array for array, the one infx_engine_index_documents builds from the same documents.  A segment written from other
-    documents is refused and leaves the engine reusable."""
+    """Two flushed segments + a live tail -> infx_engine_index_from_segments: the flushed ranges' (document, weight) postings come from the files and the host index
+    is, array for array, the one infx_engine_index_documents builds from the same documents.  A segment written from other documents is refused and leaves the
+    engine reusable."""
     s = Synth(2, docs=6000); arena, offs = s.docs()
     o = O.OracleEngine.create_default(); o.add_flat(None, arena, offs, s.field_weights); o.finalize()
     paths, bases = _flush_like(o, tmp_path, [0, 2500, 4700])                      # tail: documents [4700, 6000)
@@ -227,6 +227,50 @@ def test_an_engine_populated_from_segments_holds_the_index_of_the_documents(tmp_
         bad.index_flat_from_segments(None, arena, offs, s.field_weights, [other], [0])               # a term the documents do not produce
     bad.index_flat(None, arena, offs, s.field_weights)
     assert np.array_equal(bad.export_index()["post_doc"], b["post_doc"])
+
+
+def test_segments_keep_the_df_counter_and_the_stop_terms_of_an_unflushed_index(tmp_path):
+    """What a segment file cannot give back: the reference's df counter counts a document twice when a term's weight byte saturates inside it
+    (Term.cs:118-146, quirk Q5), and the segment writer drops the lists of terms that were stop terms AT FLUSH TIME (SegmentWriter skips df <= 0) — a term that
+    becomes a stop term later still has its list in the earlier segment.  The import accumulates every document (so df and stop decisions are those of the unflushed
+    index) and lets the segments replace the postings of their ranges: with a low stop-term limit and documents that repeat a word hundreds of times, the host
+    index is still, array for array, the one infx_engine_index_documents builds."""
+    from infidex_amd.engine import pack_texts
+    rng = np.random.default_rng(11)
+    words = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet"]
+    docs = []
+    for i in range(900):
+        k = int(rng.integers(2, 6)); t = " ".join(rng.choice(words, k))
+        if i % 37 == 5:
+            t = t + " " + " ".join(["golf"] * 300)             # the weight byte of "golf" (and of its n-grams) saturates inside this document
+        if i in (40, 300, 500, 650, 880):
+            t = t + " " + " ".join(["zulu"] * 140)             # a RARE word that saturates: it stays a live term whose df counts these documents several times
+        docs.append(t)
+    arena, offs = pack_texts(docs); fw = np.zeros(1, np.int32)
+    LIMIT = 260                                                   # stop-term limit: the frequent terms cross it in the middle of the corpus
+    cuts = [0, 150, 420, 700]
+    paths, bases = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):                       # every flush sees the index as it was THEN: documents [0, hi)
+        o = O.OracleEngine(enable_coverage=True, word_matcher=True, stop_term_limit=LIMIT)
+        a2, o2 = pack_texts(docs[:hi]); o.add_flat(None, a2, o2, fw); o.finalize()
+        p = str(tmp_path / f"flush{lo}.seg"); W.write(p, _oracle_terms(o, lo, hi), hi - lo); paths.append(p); bases.append(lo)
+    full = O.OracleEngine(enable_coverage=True, word_matcher=True, stop_term_limit=LIMIT); full.add_flat(None, arena, offs, fw); full.finalize()
+    exo = full.export_index()
+    assert int((exo["df"] < 0).sum()) > 3                         # the full corpus has stop terms ...
+    first = _read(paths[0])[1]
+    stop_names = {full.term_text(t) for t in range(full.num_terms) if exo["df"][t] < 0}
+    assert stop_names & set(first)                                # ... whose lists the FIRST flush still wrote
+    e = SearchEngine(device=-1, stop_term_limit=LIMIT); e.index_flat_from_segments(None, arena, offs, fw, paths, bases)
+    ref = SearchEngine(device=-1, stop_term_limit=LIMIT); ref.index_flat(None, arena, offs, fw)
+    a, b = e.export_index(), ref.export_index()
+    assert e.index_stats() == ref.index_stats()
+    for k in ("df", "post_off", "post_doc", "post_w", "doc_len"):
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(b[k], exo[k]), k                    # and both are the oracle's index
+    assert a["avgdl"] == b["avgdl"]
+    # the saturation is real: some list's df exceeds its posting count
+    plen = np.diff(exo["post_off"]); live = exo["df"] > 0
+    assert np.any(exo["df"][live] > plen[live])
 
 
 @pytest.mark.gpu
