@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--distinct-batches", type=int, default=0, help="distinct synthetic query batches the steps cycle through; 0 (default) = warmup + steps, "
                     "i.e. no batch — and so no misspelt word beyond what the Zipf stream itself repeats — occurs twice: planning is measured cold")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent full-index replicas instead of document shards")
+    ap.add_argument("--long-steps", type=int, default=200, help="single-GPU runs: a second, longer stream of this many fresh batches after the timed region, reported as value_long "
+                                                                "(the driver's K steps time a quarter of a second, less than the box-to-box spread); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU-baseline sample (0 = auto, ~10-30 s)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -327,6 +329,41 @@ def main():
     total_queries = args.steps * args.batch * (1 if sharded else world)
     qps = total_queries / elapsed
 
+    # long leg (after the timed region, same process, same sessions): `--long-steps` FRESH batches through the same worker loop — the steady-state rate once the
+    # fill and drain of the session pipeline no longer weigh (value_long); not the headline, which stays the driver's K steps
+    value_long = None
+    if not sharded and world == 1 and args.long_steps > 0:
+        lqa, lqo = syn.queries(args.long_steps * args.batch, qseed=5000)
+        lb = []
+        for s_ in range(args.long_steps):
+            lo, hi = s_ * args.batch, (s_ + 1) * args.batch
+            lb.append((np.ascontiguousarray(lqa[int(lqo[lo]):int(lqo[hi])]) if lqo[hi] > lqo[lo] else np.zeros(1, np.uint16), (lqo[lo:hi + 1] - lqo[lo]).astype(np.uint64)))
+        cur2 = {"next": 0}; lock2 = threading.Lock(); err2 = []; lat2 = [0.0] * len(lb)
+
+        def worker2(sess):
+            try:
+                while True:
+                    with lock2:
+                        s_ = cur2["next"]
+                        if s_ >= len(lb):
+                            return
+                        cur2["next"] = s_ + 1
+                    t_ = time.time(); sess.search_packed(lb[s_][0], lb[s_][1], k, 500); lat2[s_] = (time.time() - t_) * 1000.0
+            except Exception as ex:  # noqa: BLE001
+                err2.append(ex)
+        tl0 = time.time()
+        th2 = [threading.Thread(target=worker2, args=(se,)) for se in sessions]
+        for t in th2:
+            t.start()
+        for t in th2:
+            t.join()
+        if err2:
+            raise err2[0]
+        tl = time.time() - tl0
+        value_long = {"value": args.long_steps * args.batch / tl, "unit": "queries/s", "steps": args.long_steps, "ms_per_step": tl / args.long_steps * 1000.0,
+                      "p50_batch_latency_ms": float(np.median(lat2)), "p95_batch_latency_ms": float(np.percentile(lat2, 95)),
+                      "note": "same process and sessions, fresh batches, run after the timed region; the headline `value` is the driver's K-step form"}
+
     # roofline leg: the same batches once more on ONE session (no concurrent kernels), HIP events on the launch stream
     roof = []
     if sharded:
@@ -381,6 +418,7 @@ def main():
                                                                     else f"{world} independent replicas (one index per GPU, query stream split)")},
         "p50_batch_latency_ms": float(np.median(lat)), "p95_batch_latency_ms": float(np.percentile(lat, 95)),
         "p50_single_query_latency_ms": single_ms,
+        "value_long": value_long,
         # host phases of a batch (per session; sessions overlap): planning (text prep, term lookup, LD1 expansion, idf/roles),
         # Stage-1 host part (phase API only), Stage-2 preparation (fused pipeline: WordMatcher descriptors + PrepareQuery),
         # the wait for the device (fused: the whole device pipeline behind one synchronisation), host post-processing
@@ -451,8 +489,11 @@ def main():
             per_q = ps / len(probe)
             sample = int(max(32, min(len(texts), 20.0 * cthreads / max(per_q, 1e-6))))
         sample = min(sample, len(texts))
+        O.stage_times(reset=True)
         secs, okeys, _ = o.timed_batch(texts[:sample], k, 500, threads=cthreads)
+        stage_tot = O.stage_times(reset=True)              # thread-milliseconds per stage over the sample
         secs1, _, lat1 = o.timed_batch(texts[:min(sample, 24)], k, 500, threads=1, want_latency=True)
+        stage1t = O.stage_times(reset=True)
         # identical top-k DocumentId sets on the sample (parity is asserted in tests/; reported here)
         gk, gc = first_keys
         if flt:        # config 5: the rows are post-filtered; compare against the oracle's filtered search (sequential, smaller sample) incl. facets
@@ -471,6 +512,9 @@ def main():
                                "sample": f"first {sample} queries of the first timed batch on the same {args.docs}-document config-{args.config} index, one in-flight query per thread; "
                                          f"oracle = C++ restatement of the reference algorithm (not the .NET binary)",
                                "single_thread_qps": min(sample, 24) / secs1, "single_thread_p50_ms": float(np.median(lat1)),
+                               # where a query's time goes in the port: thread-milliseconds per query and stage (all threads of the sample run / the single-thread run)
+                               "stage_ms": {kk: v / sample for kk, v in stage_tot.items()},
+                               "stage_ms_single_thread": {kk: v / min(sample, 24) for kk, v in stage1t.items()},
                                "index_build_s": orc_box["build_s"], "identical_topk_sets": f"{same}/{sample}",
                                "parity": {"identical": same, "tie_at_cut_off": sum(1 for c in cls if c["kind"] == "tie-at-cut-off"),
                                           "identical_on_rerun": sum(1 for c in cls if c["kind"] == "identical-on-rerun"),

@@ -82,7 +82,7 @@ struct infx_session {
     // Own slice: parsed (plan, cq filled in by the collect).  A peer's: `rec` points at the query's record inside the retained blob (PlanSlab) and is parsed where
     // the plan is needed — on the planner threads of phase 0, straight into the batch's plan / coverage-query arrays — so the import itself costs a checksum.
     struct OwnPlan { QueryPlan plan; infx_cov_query cq; std::unique_ptr<infx_cov_query_long> cql; };
-    struct PlanPre { uint64_t rawHash = 0; int32_t depth = 0, covErr = 0; bool hasCov = false, longCov = false; const uint8_t* rec = nullptr; uint32_t recLen = 0, covOff = 0; std::unique_ptr<OwnPlan> own; };
+    struct PlanPre { uint64_t rawHash = 0; int32_t depth = 0, covErr = 0; bool hasCov = false, longCov = false, planTaken = false;      /* planTaken: own->plan was moved into a batch */ const uint8_t* rec = nullptr; uint32_t recLen = 0, covOff = 0; std::unique_ptr<OwnPlan> own; };
     struct PlanSlab { std::vector<uint8_t> bytes; std::vector<PlanPre> pre; };
     std::vector<std::shared_ptr<PlanPre>> planPre;
     uint32_t planFromExchange = 0, planFromPeers = 0;      // last phase 0: queries planned from planPre / of them imported from another rank
@@ -512,10 +512,10 @@ static int32_t ph_plan(infx_engine* e, infx_session* S, uint32_t nq, const uint1
         for (int64_t i = b; i < en; i++) {
             const u16* rp = (const u16*)q_arena + q_offs[i]; const size_t rl = (size_t)(q_offs[i + 1] - q_offs[i]);
             infx_session::PlanPre* pre = havePre ? S->planPre[i].get() : nullptr;
-            if (pre && pre->depth == depth && pre->rawHash == raw_hash((const uint16_t*)rp, rl)) {
+            if (pre && !pre->planTaken && pre->depth == depth && pre->rawHash == raw_hash((const uint16_t*)rp, rl)) {
                 // (the entry keeps its coverage query — parsed, or where it sits in the record — for build_fused_inputs)
                 if (pre->rec) { const char* why = parse_plan_record(ix, pre->rec, pre->recLen, depth, plans[i], pre->hasCov, pre->covErr, pre->covOff, pre->longCov); if (why) badRec.store(why); }
-                else plans[i] = std::move(pre->own->plan);
+                else { plans[i] = std::move(pre->own->plan); pre->planTaken = true; }      // a second phase 0 on the same entries (INFX_PHASED, an empty batch: build_fused_inputs did not clear them) plans afresh instead of taking the moved-from plan
                 nPre++; if (S->planPeer[i]) nPeer++;
             } else {
                 if (havePre) S->planPre[i] = nullptr;      // not this query's: build_fused_inputs must not take its coverage query either

@@ -358,6 +358,7 @@ static int s2_pool() { static const int w = [] { const char* e = getenv("INFX_S2
 // The table is consumed: the next Stage-2 call starts without one.
 #define S2_LAUNCH_LONGQ(...) do { if (s->nLongQ) { \
     k_stage2<S2_MAXD, 2, false, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)nullptr, (uint32_t*)nullptr, 0u, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
+    (void)hipMemsetAsync(s->dHugeCnt, 0, 4, s->st);      /* the long-query rows get the whole token-table pool, not what the ordinary rows' pool pass left of it */ \
     k_stage2<S2_HUGE_TOKENS, 1, true, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
     s->nLongQ = 0; } } while (0)
 static int32_t s2_huge_ready(infx_stream* s);
@@ -1252,9 +1253,13 @@ int32_t infx_stage2_long_queries(infx_stream* s, uint32_t n, const infx_cov_quer
     infx_index* ix = s->ix;
     HIPCHK(enter_device(ix->cfg.device));
     // (no pin_reset: this call sits between the phases of a batch, whose pending downloads must survive it; its own upload is staged behind theirs)
-    for (uint32_t i = 0; i < n; i++)
+    for (uint32_t i = 0; i < n; i++) {
         if (q[i].num_tokens < 0 || q[i].num_tokens > INFX_LONGQ_TOKENS || q[i].text_len < 0 || q[i].text_len > INFX_LONGQ_CHARS || q[i].num_fusion_tokens < 0 || q[i].num_fusion_tokens > 2 * INFX_LONGQ_TOKENS)
             return fail(INFX_EUNSUPPORTED, "query exceeds the long Stage-2 envelope%s");
+        // the kernel dereferences text + tok_off: a token table that points outside the text would read out of bounds on the device
+        for (int32_t t = 0; t < q[i].num_tokens; t++) if ((int32_t)q[i].tok_off[t] + (int32_t)q[i].tok_len[t] > q[i].text_len) return fail(INFX_EINVAL, "long query: a token lies outside the query text%s");
+        for (int32_t t = 0; t < q[i].num_fusion_tokens; t++) if ((int32_t)q[i].ftok_off[t] + (int32_t)q[i].ftok_len[t] > q[i].text_len) return fail(INFX_EINVAL, "long query: a fusion token lies outside the query text%s");
+    }
     GROW(s->dCovQL, s->capCovQL, (size_t)n * sizeof(infx_cov_query_long));
     UP(s->dCovQL, q, (size_t)n * sizeof(infx_cov_query_long));
     k_fold_ic_longq<<<n, WAVE, 0, s->st>>>((infx_cov_query_long*)s->dCovQL, n);
@@ -1275,6 +1280,9 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
         if (q[i].reserved != 0) { if (q[i].reserved < 0 || (uint32_t)q[i].reserved > s->nLongQ) return fail(INFX_EINVAL, "query refers to a missing long-query record (infx_stage2_long_queries)%s"); continue; }
         if (q[i].num_tokens > INFX_MAX_QUERY_TOKENS || q[i].text_len > INFX_MAX_QUERY_CHARS || q[i].num_fusion_tokens > 2 * INFX_MAX_QUERY_TOKENS)
             return fail(INFX_EUNSUPPORTED, "query exceeds the Stage-2 envelope (hand it over as a long query: infx_stage2_long_queries)%s");
+        if (q[i].num_tokens < 0 || q[i].text_len < 0 || q[i].num_fusion_tokens < 0) return fail(INFX_EINVAL, "negative count in a coverage query%s");
+        for (int32_t t = 0; t < q[i].num_tokens; t++) if ((int32_t)q[i].tok_off[t] + (int32_t)q[i].tok_len[t] > q[i].text_len) return fail(INFX_EINVAL, "coverage query: a token lies outside the query text%s");
+        for (int32_t t = 0; t < q[i].num_fusion_tokens; t++) if ((int32_t)q[i].ftok_off[t] + (int32_t)q[i].ftok_len[t] > q[i].text_len) return fail(INFX_EINVAL, "coverage query: a fusion token lies outside the query text%s");
     }
     GROW(s->dCovQ, s->capCovQ, (size_t)nq * sizeof(infx_cov_query));
     GROW(s->dCovC, s->capCovC, (size_t)ncand * sizeof(infx_cov_cand));

@@ -91,6 +91,11 @@ class TorchComm:
         o = out.numpy().reshape(self.world, max(m, 1))
         return [o[r, :int(sizes[r].item())] for r in range(self.world)]
 
+    def allreduce_min_i32(self, a: np.ndarray) -> np.ndarray:
+        t = self.torch.from_numpy(np.ascontiguousarray(a.view(np.int32))).clone().to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return t.cpu().numpy().view(a.dtype).reshape(a.shape)
+
     def max_i64(self, v: int) -> int:
         t = self.torch.tensor([v], dtype=self.torch.int64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -461,7 +466,20 @@ class ShardedSearcher:
         # the plan exchange: rank r plans its 1/W slice of every batch, the ranks all-gather the plans (INFX_PLAN_EXCHANGE=0 or partition_planning=False:
         # every rank plans every query).  With the dictionaries on the device (the default) the blobs carry the token-level plans and the
         # coverage query contexts; with host lookups also the LD1 expansions and the WordMatcher descriptors.
-        self.partition_planning = partition_planning and comm.world > 1 and os.environ.get("INFX_PLAN_EXCHANGE", "1") != "0"
+        # Default (INFX_PLAN_EXCHANGE unset): on only where its projected gain is large and its measured cost small — W >= 4 ranks sharing a node whose CPU quota
+        # leaves a rank at most four planner threads (per-rank host planning 10 us -> 5.3 + 4.7 / W us per query).  The only wall-clock
+        # measurement in the tree, two ranks on one GPU, is slower with it (27.5 k vs 30.0 k queries/s, profiles/r05_bench_two_ranks_10m_plan_exchange_*.json),
+        # so small worlds plan every query on every rank.  INFX_PLAN_EXCHANGE=1 / 0 forces it on / off.
+        env = os.environ.get("INFX_PLAN_EXCHANGE", "")
+        if env in ("0", "1"):
+            want = env == "1"
+        else:
+            try:
+                cpus = len(os.sched_getaffinity(0))
+            except Exception:
+                cpus = os.cpu_count() or 1
+            want = comm.world >= 4 and cpus // max(1, comm.world) <= 4
+        self.partition_planning = bool(partition_planning and comm.world > 1 and want)
         K = max(1, int(sessions)) if self.native else 1
         self.sessions = [ShardSession(engine) for _ in range(K)]
         self.sess = self.sessions[0]
@@ -482,6 +500,16 @@ class ShardedSearcher:
                     print(f"[infidex] plan exchange off: gloo group could not be created ({ex})", file=sys.stderr)
                     self.partition_planning = False
             self.plan_groups.append(g)
+        if comm.world > 1 and partition_planning and want:
+            # the fallback is a decision of the WORLD, not of a rank: one rank without its groups while the others exchange would mismatch every collective behind it
+            # (and hang until INFX_COMM_TIMEOUT_S).  All ranks reach this all-reduce — group creation above is attempted by all or none — and take the minimum.
+            import numpy as _np
+            ok = _np.array([1 if self.partition_planning else 0], _np.int32)
+            ok = comm.allreduce_min_i32(ok)
+            if int(ok[0]) == 0 and self.partition_planning:
+                import sys
+                print("[infidex] plan exchange off: another rank could not create its gloo groups", file=sys.stderr)
+            self.partition_planning = bool(int(ok[0]))
         if not self.partition_planning:
             self.plan_groups = [None] * len(self.sessions)
         self.plan_group = self.plan_groups[0]

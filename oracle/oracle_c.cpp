@@ -213,6 +213,11 @@ int32_t orc_coverage_standalone(const uint16_t* q, int32_t ql, const uint16_t* d
     return f.CoverageScore;
 }
 
+// per-stage nanoseconds summed over all threads since the last reset (stage1.hpp StageClock): planning, candidate selection, BM25+ scoring, WordMatcher, coverage
+void orc_stage_times(double* out_ms5, int32_t reset) {
+    for (int i = 0; i < 5; i++) { out_ms5[i] = (double)stage_ns(i).load() * 1e-6; if (reset) stage_ns(i).store(0); }
+}
+
 // ---- timed batch for bench.py's cpu_baseline leg ---------------------------------------------------
 // Runs nq queries (concatenated UTF-16 with offsets) on `threads` threads (one in-flight query per thread, each
 // with its own Stage1 scratch — the reference's concurrent-reader model, SearchEngine.cs:258). Returns seconds.

@@ -131,7 +131,10 @@ struct Engine {
         int depth = qp.coverageDepth;
         if ((int)top.size() > depth) top.resize(depth);
         std::vector<int32_t> wmIds;
+        StageClock clk_;
         if (ix.cfg.wordMatcher) wm.execute(searchText, cs.CoverPrefixSuffix, wmIds);
+        clk_.lap(3);
+        struct CovLap { StageClock& c; ~CovLap() { c.lap(4); } } covLap_{clk_};      // the rest of the coverage stage
         // BuildDocumentKeyIndex: insertion-ordered unique keys: top candidates first, then WM ids ascending
         std::unordered_map<int64_t, int> keyToIndex;
         int next = 0;

@@ -12,12 +12,22 @@
 //                                         pruning heap (BCL PriorityQueue, Q10)
 //   Core/TopKHeap.cs, Core/ScoreEntry.cs:25-36, Scoring/SegmentProcessor.cs:15-37
 #pragma once
+#include <atomic>
+#include <chrono>
 #include "index.hpp"
 #include <list>
 #include <memory>
 #include <limits>
 
 namespace orc {
+
+// Where a query's time goes (bench.py's cpu_baseline.stage_ms): nanoseconds summed over all threads — [0] planning (tokens, term lookup, fuzzy expansion, idf),
+// [1] candidate selection (TieredCandidateSelector), [2] BM25+ scoring and the top-k heap (Bm25Scorer), [3] WordMatcher, [4] coverage + fusion (Stage 2).
+inline std::atomic<unsigned long long>& stage_ns(int i) { static std::atomic<unsigned long long> a[5]; return a[i]; }
+struct StageClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(int i) { const auto n = std::chrono::steady_clock::now(); stage_ns(i).fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(), std::memory_order_relaxed); t = n; }
+};
 
 constexpr int NO_MORE_DOCS = std::numeric_limits<int>::max();
 
@@ -338,7 +348,10 @@ struct Stage1 {
         if (terms.empty() || ix.N == 0) return {};
         float avgdl = ix.avgdl > 0.f ? ix.avgdl : 1.f;
         upperBounds.assign((size_t)ix.N, 0.f);
+        StageClock clk_;
         std::vector<int32_t> cand = select_candidates(terms, topK, originalQuery);
+        clk_.lap(1);
+        struct ScoreLap { StageClock& c; ~ScoreLap() { c.lap(2); } } scoreLap_{clk_};      // everything from here to the return is scoring
         stats.candidates = (long)cand.size();
         int T = (int)terms.size();
         std::vector<float> suffix(T + 1, 0.f);
@@ -402,6 +415,7 @@ struct Stage1 {
 
     // VectorModel.SearchWithMaxScore
     std::vector<ScoreEntry> search_with_maxscore(uview queryText, int topK) {
+        StageClock planClk_;
         stats = Stage1Stats();
         std::vector<RawToken> raw; raw_tokens(queryText, raw);
         dotnet::sort(raw, [](const RawToken& a, const RawToken& b) {
@@ -453,6 +467,7 @@ struct Stage1 {
             else if (s.termId >= 0) infos.push_back({PostingSrc{ix.pdoc(s.termId), ix.pw(s.termId), ix.plen(s.termId)}, df, idf, maxScore, s.termId});
         }
         lastTerms = infos;
+        planClk_.lap(0);
         return bm25_search(infos, topK, queryText);
     }
     std::vector<TermScoreInfo> lastTerms;   // exposed for tests / parity harness

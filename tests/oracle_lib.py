@@ -214,6 +214,13 @@ class OracleEngine:
         return secs, keys, lat
 
 
+def stage_times(reset=True):
+    """Milliseconds the oracle spent per stage, summed over its threads, since the last reset: planning, candidate selection, BM25+ scoring, WordMatcher, coverage."""
+    out = np.zeros(5, np.float64)
+    lib().orc_stage_times(_p(out, C.c_double), int(reset))
+    return dict(zip(("planning", "candidate_selection", "bm25_scoring", "wordmatcher", "coverage"), out.tolist()))
+
+
 def levenshtein(a, b, max_err=2**31 - 1, ignore_case=False):
     x, y = u16(a), u16(b)
     return lib().orc_levenshtein(_p(x, C.c_uint16), len(x), _p(y, C.c_uint16), len(y), max_err, int(ignore_case))

@@ -31,7 +31,7 @@ a, o = pack_texts(texts)
 batches = [(a, o), pack_texts(texts[:100]), pack_texts(texts[100:])]
 res = list(searcher.search_stream(batches, 20, 500))             # three batches in flight: a session, a stream and a communicator each
 single = searcher.search_packed(a, o, 20, 500)
-# plan exchange on (default: each rank plans its half of the batch — text preparation, term lookups, coverage query contexts — and the blobs are exchanged
+# plan exchange on (INFX_PLAN_EXCHANGE=1 here; by default only worlds of >= 4 ranks with few CPUs per rank switch it on: each rank plans its half of the batch — text preparation, term lookups, coverage query contexts — and the blobs are exchanged
 # on the planning group) and off (every rank plans the whole batch) must agree
 assert eng.device_lookups() and searcher.partition_planning and searcher.native and len(searcher.sessions) == 3
 used, peers = searcher.plan_exchange_stats()
@@ -55,7 +55,7 @@ def test_two_ranks_equal_the_oracle(tmp_path):
     from tools.synth import Synth
     out = str(tmp_path / "r0.npz")
     env = dict(os.environ); env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env["INFX_THREADS"] = "4"
+    env["INFX_THREADS"] = "4"; env["INFX_PLAN_EXCHANGE"] = "1"      # (off by default in a world of two: forced on, this test is its GPU coverage)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
            "-c", RANK_SCRIPT, out] if False else None
     script = str(tmp_path / "rank.py"); open(script, "w").write(RANK_SCRIPT)
@@ -78,7 +78,7 @@ def test_bench_gpus_2():
     one GPU under RCCL) and reports n_gpus == 2 with the same collectives issued on both ranks."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ); env.update({"INFX_DIST_BACKEND": "gloo", "MASTER_PORT": "29641", "INFX_THREADS": "4"})
+    env = dict(os.environ); env.update({"INFX_DIST_BACKEND": "gloo", "MASTER_PORT": "29641", "INFX_THREADS": "4", "INFX_PLAN_EXCHANGE": "1"})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--docs", "140000", "--steps", "2", "--warmup", "1", "--batch", "200", "--no-cpu-baseline"],
