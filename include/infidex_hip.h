@@ -411,9 +411,6 @@ int32_t infx_last_exact_replays(infx_stream* s, uint32_t* n);
 int32_t infx_last_replay_stats(infx_stream* s, float* ms, uint32_t* why3);
 /* ... and its parts: the scan (k_ex_walk x2 + k_ex_prefix + k_ex_theta), k_ex_chunk (three launches), k_ex_heap, k_exact1 (ms, HIP events on the stream). */
 int32_t infx_last_replay_breakdown(infx_stream* s, float* ms4);
-/* Self-test of the library's own fp32 division sequence (k_accumulate A/B build, csrc/stage1.hip.inc acc_div) against the compiler's division on the
- * device: 256 tf bytes x 65 536 denominators; *mismatches == 0 means bit-identical. */
-int32_t infx_selftest_div(int32_t device, uint32_t* mismatches);
 
 #ifdef __cplusplus
 }

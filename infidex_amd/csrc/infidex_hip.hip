@@ -2028,16 +2028,6 @@ int32_t infx_last_replay_stats(infx_stream* s, float* ms, uint32_t* why3) {
     if (why3) { why3[0] = s->lastFlagWhy[0]; why3[1] = s->lastFlagWhy[1]; why3[2] = s->lastFlagWhy[2]; }
     return INFX_OK;
 }
-// acc_div (stage1.hip.inc) against the compiler's fp32 division on the device: every tf byte x 65 536 denominators; *mismatches must come back 0
-int32_t infx_selftest_div(int32_t device, uint32_t* mismatches) {
-    if (!mismatches) return fail(INFX_EINVAL, "null argument%s");
-    HIPCHK(enter_device(device));
-    uint32_t* d = nullptr; HIPCHK(hipMalloc((void**)&d, 4)); HIPCHK(hipMemset(d, 0, 4));
-    k_div_selftest<<<dim3(256, 256), 256>>>(d);
-    hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(mismatches, d, 4, hipMemcpyDeviceToHost); (void)hipFree(d);
-    HIPCHK(e1); HIPCHK(e2);
-    return INFX_OK;
-}
 int32_t infx_last_replay_breakdown(infx_stream* s, float* ms4) {      // scan (k_ex_walk x2 + k_ex_prefix + k_ex_theta), k_ex_chunk (three launches), k_ex_heap, k_exact1 of the last batch
     if (!s || !ms4) return fail(INFX_EINVAL, "null argument%s");
     if (s->timedReplayParts) {

@@ -474,10 +474,7 @@ class ShardedSearcher:
         if env in ("0", "1"):
             want = env == "1"
         else:
-            try:
-                cpus = len(os.sched_getaffinity(0))
-            except Exception:
-                cpus = os.cpu_count() or 1
+            cpus = int(engine.L.infx_engine_effective_cpus())      # hardware threads capped by affinity AND the cgroup CPU quota (the boxes' quota is 16 of 256)
             want = comm.world >= 4 and cpus // max(1, comm.world) <= 4
         self.partition_planning = bool(partition_planning and comm.world > 1 and want)
         K = max(1, int(sessions)) if self.native else 1

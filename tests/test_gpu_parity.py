@@ -488,16 +488,6 @@ def test_characters_outside_the_bmp_on_gpu():
         assert np.allclose([x.score for x in r.records], w["scores"], rtol=0, atol=FINAL_ATOL), (q, r.records, w)
 
 
-def test_library_division_sequence_is_bit_identical_to_the_compilers():
-    """acc_div (k_accumulate's A/B build: the compiler's fp32 division without its v_div_scale / v_div_fixup frame) == `/` for every tf byte and 65 536
-    denominators spread over [0.25, 1e5]: 16.7 M quotients compared on the device."""
-    import ctypes as C
-    from infidex_amd.engine import load_library
-    L = load_library(); n = C.c_uint32(12345)
-    assert L.infx_selftest_div(0, C.byref(n)) == 0
-    assert n.value == 0, n.value
-
-
 def test_high_term_frequencies():
     """Documents that repeat a word up to 150 times: byte tf values from 2 to ~190 (Term.cs:87-109).  The replay kernels get tf >= 3 through the
     per-row exception records (k_accumulate) or the posting-list lookup."""

@@ -92,3 +92,28 @@ def test_bench_gpus_2():
     px = [c.pop("plan_exchange") for c in cs]
     assert len(cs) == 2 and cs[0] == cs[1], cs
     assert all(p["on"] and p["queries_planned_from_exchange"] == 200 and p["of_them_imported_from_peers"] == 100 for p in px), px      # each rank planned half of the last batch
+
+
+def test_bench_gpus_8():
+    """`python bench.py --gpus 8`, started bare as the driver starts it, on EIGHT ranks (gloo: eight ranks share this one GPU) over 600 k documents (10 containers:
+    every rank owns one or two): the line reports n_gpus == 8, the eight ranks issued the same collectives, and the plan exchange — on by default in a world of
+    eight with two planner threads per rank — fed every query of the last batch, seven eighths of them from peers.  What the driver's first 8-GPU run exercises
+    beyond this is RCCL itself."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.update({"INFX_DIST_BACKEND": "gloo", "MASTER_PORT": "29651", "INFX_THREADS": "2"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "INFX_PLAN_EXCHANGE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--docs", "600000", "--steps", "2", "--warmup", "1", "--batch", "160", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0
+    cs = d["collectives_per_rank"]
+    px = [c.pop("plan_exchange") for c in cs]
+    assert len(cs) == 8 and all(c == cs[0] for c in cs), cs
+    if px[0]["on"]:          # (a box whose quota leaves a rank more than four CPUs plans every query everywhere: the rule of ShardedSearcher)
+        assert all(p["on"] and p["queries_planned_from_exchange"] == 160 and p["of_them_imported_from_peers"] == 140 for p in px), px
+    assert len(d["stage_ms_per_step_per_rank"]) == 8
