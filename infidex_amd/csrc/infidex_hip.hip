@@ -181,6 +181,7 @@ __device__ __forceinline__ uint64_t lower_bound_i32(const int32_t* a, uint64_t l
 }
 
 #include "stage1.hip.inc"
+#include "stage1_sparse.hip.inc"
 #include "exact1.hip.inc"
 #include "exact3.hip.inc"
 #include "exactsh.hip.inc"
@@ -277,6 +278,7 @@ struct infx_stream {
     struct PendingOut { void* dst; const void* src; size_t bytes; }; std::vector<PendingOut> pendingOut; bool unsynced = false;
     std::vector<uint32_t> unionCount; std::vector<unsigned long long> unionBase{0};   // device-resident unions of the last infx_union_build
     void* dCounts = nullptr; size_t capCounts = 0;
+    void* dDense = nullptr; size_t capDense = 0;      // k_accumulate_sparse -> k_accumulate hand-over flags, one byte per (query, stripe)
     void* dCovQ = nullptr; size_t capCovQ = 0;
     void* dCovQL = nullptr; size_t capCovQL = 0; uint32_t nLongQ = 0;      // infx_stage2_long_queries: the long-query table of the next Stage-2 call
     void* dCovC = nullptr; size_t capCovC = 0;
@@ -498,19 +500,39 @@ template <int R> static bool acc_lds_layout_ok() {
     }();
     return ok;
 }
+// Two kernels share the (query, stripe) pairs of a batch by candidate density (INFX_ACC_SPARSE_T candidates per stripe, default 64, at most 64; 0: one kernel):
+//   k_accumulate_sparse (stage1_sparse.hip.inc)  stripes of <= T candidates: the candidates look their postings up (binary search of the stripe slice, one per lane)
+//   k_accumulate        (stage1.hip.inc)         the rest: byte scatter + probe per (list, range) — cheapest per candidate once a range holds dozens of them
+static int acc_sparse_t() { static const int v = [] { const char* e = getenv("INFX_ACC_SPARSE_T"); const int x = e ? atoi(e) : 64; return std::max(0, std::min(64, x)); }(); return v; }
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp, int maxRef) {
     (void)maxRef;
     if (!acc_lds_layout_ok<R>()) { s->accLayoutBad = true; return; }
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
-    const int stripe = acc_stripe();
+    const int sparseT = acc_sparse_t();
+    const int stripe = sparseT > 0 ? std::max(1, std::min(4, 65536 / R)) : acc_stripe();      // (the two kernels split the same stripes: a power of two)
+    const int nStripes = (s->ix->d.nRanges + stripe - 1) / stripe;
+    const uint64_t blocks = (uint64_t)nq * 8u * ((nStripes + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
+    const uint8_t* dense = nullptr;
+    if (sparseT > 0) {
+        if (grow(s, &s->dDense, &s->capDense, (size_t)nq * nStripes)) { s->accLayoutBad = true; return; }
+        hipMemsetAsync(s->dDense, 0, (size_t)nq * nStripes, s->st);
+        const size_t sw = (size_t)stripe * (R / 32);
+        const size_t ldsS = (sw + 64 + 4) * 4 + INFX_NCLASS * 4 + WAVE * 2;      // padded bitmap (one pad word per lane) | class histogram | slot table
+        if (ar.maskWords == 2)
+            k_accumulate_sparse<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
+                                                                                         (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, (uint8_t*)s->dDense, (uint32_t)sparseT, nStripes);
+        else
+            k_accumulate_sparse<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
+                                                                                         (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, (uint8_t*)s->dDense, (uint32_t)sparseT, nStripes);
+        dense = (const uint8_t*)s->dDense;
+    }
     const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
-    const uint64_t blocks = (uint64_t)nq * 8u * (((s->ix->d.nRanges + stripe - 1) / stripe + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
     if (ar.maskWords == 2)
         k_accumulate<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats);
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nStripes);
     else
         k_accumulate<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats);
+                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nStripes);
     if (dbgSkip & 8) { unsigned long long h[4] = {0, 0, 0, 0}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 32, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 32);
         fprintf(stderr, "[infx] k_accumulate stats: %llu ranges with candidates (%llu blocks), %.2f rounds/range, %.1f candidates/range\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0); }
 }
@@ -996,7 +1018,7 @@ void infx_stream_destroy(infx_stream* s) {
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
                   s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters, s->exContEnd, s->dExProf, s->dSelOrder,
-                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount};
+                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount, s->dDense};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
     for (void* p : s->parked) hipFree(p);
