@@ -500,10 +500,10 @@ template <int R> static bool acc_lds_layout_ok() {
     }();
     return ok;
 }
-// Two kernels share the (query, stripe) pairs of a batch by candidate density (INFX_ACC_SPARSE_T candidates per stripe, default 64, at most 64; 0: one kernel):
+// Two kernels share the (query, stripe) pairs of a batch by candidate density (INFX_ACC_SPARSE_T candidates per stripe, default 96 — measured 64: 6.27, 96: 6.18, 128: 6.20, 192: 6.31, 256: 6.41, 512: 6.85 ms for the pair; 0: one kernel, 7.21 ms):
 //   k_accumulate_sparse (stage1_sparse.hip.inc)  stripes of <= T candidates: the candidates look their postings up (binary search of the stripe slice, one per lane)
 //   k_accumulate        (stage1.hip.inc)         the rest: byte scatter + probe per (list, range) — cheapest per candidate once a range holds dozens of them
-static int acc_sparse_t() { static const int v = [] { const char* e = getenv("INFX_ACC_SPARSE_T"); const int x = e ? atoi(e) : 64; return std::max(0, std::min(64, x)); }(); return v; }
+static int acc_sparse_t() { static const int v = [] { const char* e = getenv("INFX_ACC_SPARSE_T"); const int x = e ? atoi(e) : 96; return std::max(0, std::min(4096, x)); }(); return v; }
 template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, int maxT, int useGrp, int maxRef) {
     (void)maxRef;
     if (!acc_lds_layout_ok<R>()) { s->accLayoutBad = true; return; }
@@ -517,13 +517,15 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
         if (grow(s, &s->dDense, &s->capDense, (size_t)nq * nStripes)) { s->accLayoutBad = true; return; }
         hipMemsetAsync(s->dDense, 0, (size_t)nq * nStripes, s->st);
         const size_t sw = (size_t)stripe * (R / 32);
-        const size_t ldsS = (sw + 64 + 4) * 4 + INFX_NCLASS * 4 + WAVE * 2;      // padded bitmap (one pad word per lane) | class histogram | slot table
+        const int maxTl = (std::min(64, std::max(1, maxT)) + 3) & ~3;
+        static const int dbgS = [] { const char* e = getenv("INFX_ACCS_SKIP"); return e ? atoi(e) : 0; }();      // kernel ablation for profiling only
+        const size_t ldsS = (sw + 64 + 4) * 4 + INFX_NCLASS * 4 + WAVE * 2 + WAVE * 12 + (size_t)WAVE * maxTl + (size_t)64 * maxTl;      // padded bitmap (one pad word per lane) | class histogram | slot table | slice table | hit matrix | slice samples
         if (ar.maskWords == 2)
             k_accumulate_sparse<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
-                                                                                         (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, (uint8_t*)s->dDense, (uint32_t)sparseT, nStripes);
+                                                                                         (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, (uint8_t*)s->dDense, (uint32_t)sparseT, nStripes, maxTl, dbgS);
         else
             k_accumulate_sparse<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
-                                                                                         (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, (uint8_t*)s->dDense, (uint32_t)sparseT, nStripes);
+                                                                                         (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, (uint8_t*)s->dDense, (uint32_t)sparseT, nStripes, maxTl, dbgS);
         dense = (const uint8_t*)s->dDense;
     }
     const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
@@ -1701,6 +1703,9 @@ int32_t infx_search_fused(infx_stream* s, uint32_t nd, const infx_query* q, uint
     static const bool turnstile = [] { const char* e = getenv("INFX_TURNSTILE"); return !(e && e[0] == '0'); }();
     {
         std::unique_lock<std::mutex> turn(ix->turnMu, std::defer_lock);
+        // (round 6 measured the wait BETWEEN k_accumulate_sparse and the streaming k_accumulate — the address-path-bound kernel of this batch beside the vector-bound
+        //  kernels of the batch before: no difference, 94.7 / 94.4 k against 95.8 / 94.3 k queries/s over 200 batches; the streaming kernel's four 128-register
+        //  waves per SIMD leave no room for a second kernel's waves)
         if (turnstile) { turn.lock(); if (ix->turnEvent && ix->turnEvent != s->evTurn) HIPCHK(hipStreamWaitEvent(s->st, ix->turnEvent, 0)); }
         if (nd) { int32_t rc_ = acc_enqueue(s, nd, q, nterms, terms, 0, nullptr); if (rc_) return rc_; }
         else { HIPCHK(hipEventRecord(s->evA0, s->st)); HIPCHK(hipEventRecord(s->evA1, s->st)); }

@@ -535,7 +535,7 @@ np.savez(sys.argv[1], **out)
 '''
     res = []
     variants = [dict(),                                                        # shipping split: stripes of <= 64 candidates search, the rest stream
-                dict(INFX_ACC_SPARSE_T="0"), dict(INFX_ACC_SPARSE_T="8"), dict(INFX_ACC_SPARSE_T="33"),      # one kernel (streaming) / other split points
+                dict(INFX_ACC_SPARSE_T="0"), dict(INFX_ACC_SPARSE_T="8"), dict(INFX_ACC_SPARSE_T="33"), dict(INFX_ACC_SPARSE_T="150"), dict(INFX_ACC_SPARSE_T="4096"),      # one kernel (streaming) / other split points (beyond 64: several rounds per stripe)
                 dict(INFX_ACC_SPARSE_T="0", INFX_ACC_SKIP="32"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="1"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="2"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="8")]
     for vi, var in enumerate(variants):
         env = dict(os.environ); env.update(var)
