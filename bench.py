@@ -31,14 +31,15 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 HBM_COPY_GBS = 6290.0     # the measured copy rate of the same guide: SURVEY 8(d) asks for the fraction of it next to the fraction of the spec
 
 
-PMC_FILE = "r05_pmc.json"
+PMC_FILE = "r06_pmc.json"
 
 
 def kernel_sha16():
-    """sha256 (16 hex digits) of what decides k_accumulate's traffic: the kernel source and its launch code (grid, XCD-aware block map, LDS size)."""
+    """sha256 (16 hex digits) of what decides the traffic of the Stage-1 accumulation (k_accumulate_sparse + k_accumulate): the kernel sources and their launch code (grid, XCD-aware block map, split point, LDS sizes)."""
     import hashlib
     csrc = os.path.join(ROOT, "infidex_amd", "csrc")
     h = hashlib.sha256(open(os.path.join(csrc, "stage1.hip.inc"), "rb").read())
+    h.update(open(os.path.join(csrc, "stage1_sparse.hip.inc"), "rb").read())
     src = open(os.path.join(csrc, "infidex_hip.hip")).read()
     a = src.index("template <int R> static void launch_acc("); b = src.index("// k_exact1 behind k_select", a)
     h.update(src[a:b].encode())
@@ -425,17 +426,18 @@ def main():
         "stage_ms_per_step": stage_me,
         # "bound": what limits the kernel by the counters of profiles/ (instruction issue), NOT what it is priced against: `peak` stays the HBM roofline the
         # path is bounded by in principle (byte streaming, no MFMA work), so `frac` is the achieved fraction of the HBM roofline by algorithmic bytes
-        "roofline": {"kernel": "k_accumulate", "bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"kernel": "Stage-1 accumulation = k_accumulate_sparse + k_accumulate (two kernels split the (query, stripe) pairs of a launch by candidate count; one after the other on the "
+                               "stream, timed as one span)", "bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS, "traffic": None,
-                     "limiter": "instruction issue and latency, not bandwidth: the kernel is priced against the HBM roofline (byte streaming, no MFMA work) but its "
-                                "time is set by the VALU / SALU / LDS instructions of the (posting list, doc range) visits - vector ALUs 72 % busy, 46 % of a wave's time in "
-                                "s_waitcnt (profiles/r05_final_10m.md, r05_pmc.json); a kernel that only loads random 512-byte slices reaches 5.2-5.7 TB/s on this GPU (tools/bench_slices.hip)",
+                     "limiter": "not bandwidth: the accumulation is priced against the HBM roofline (byte streaming, no MFMA work) by SURVEY 8(d)'s algorithmic bytes, but the streaming "
+                                "kernel (dense stripes: ~4.0 ms) is bound by VALU / SALU issue and latency of its (posting list, doc range) visits, and the sparse kernel (stripes of <= 96 "
+                                "candidates: ~2.0 ms) by the latency of its dependent lookups - it does not stream its lists at all (profiles/r06_final_10m.md, r06_pmc.json)",
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": acc_ms,
                      "streamed_bytes_per_launch": streamed, "stage1_candidates_per_launch": float(np.mean([t["stage1_candidates"] for t in roof])),
                      "stage2_rows_per_launch": float(np.mean([t["stage2_candidates"] for t in roof])), "exact_replays_per_launch": float(np.mean([t["exact_replays"] for t in roof])), "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
                      "other_kernels_ms": {kk: float(np.mean([t[kk + "_ms"] for t in roof])) for kk in ("k_select", "k_replay", "k_prep2", "k_stage2", "k_finalize")},
                      "replay_flag_reasons_per_launch": {kk: float(np.mean([t["flag_" + kk] for t in roof])) for kk in ("plateau", "band", "unknown")},
-                     "note": "achieved = SURVEY 8(d) algorithmic bytes / k_accumulate duration (HIP events on the launch stream, uncontended launch)"},
+                     "note": "achieved = SURVEY 8(d) algorithmic bytes / duration of the two accumulation kernels together (HIP events on the launch stream around both, uncontended launch); the rocprofv3 kernel-trace averages of k_accumulate_sparse and k_accumulate add up to it"},
         "roofline_by_kernel": roofline_by_kernel(roof),
         "planning_lookups": lk,
         "setup_s": {"corpus_gen": t_gen, "index_build_and_upload": t_index, "host_threads": bthreads},
