@@ -55,6 +55,7 @@ template <class A> void ar(A& a, HostIndex& ix) {
     ar(a, ix.prefixKeys); a.vec(ix.prefixPop); a.vec(ix.prefixSetId); a.vec(ix.psOff); a.vec(ix.psDocs);
     ar(a, ix.wmExact); ar(a, ix.wmLd1); a.vec(ix.affixFwd); a.vec(ix.affixRev);
     ar(a, ix.words); a.vec(ix.wordDf); a.vec(ix.wordLastDoc); a.vec(ix.wordIdf);
+    ar(a, ix.icWords); a.vec(ix.icWordIdf);
 }
 // what the arrays depend on besides the documents: FNV-1a over the configuration fields build_index reads (threads excluded: the build is
 // deterministic in the thread count) and the synonym pairs
@@ -67,7 +68,7 @@ inline uint64_t config_signature(const HostConfig& c, uint64_t synHash) {
     return h;
 }
 struct Header { char magic[8]; uint32_t version, keysAreIds; uint64_t configSig, fingerprint, payloadBytes, payloadSum; };
-constexpr uint32_t VERSION = 2;
+constexpr uint32_t VERSION = 3;      // 3: OrdinalIgnoreCase word classes (icWords)
 
 // returns an empty string on success, else what went wrong
 inline std::string save(const char* path, HostIndex& ix, bool keysAreIds, uint64_t configSig, uint64_t fingerprint) {

@@ -23,6 +23,8 @@
 #include <cstdlib>
 #include <cstdio>
 #include <sched.h>
+#include <unordered_map>
+#include <string>
 #include <memory>
 #include <condition_variable>
 #include <mutex>
@@ -253,6 +255,9 @@ struct HostIndex {
     std::vector<uint32_t> affixFwd, affixRev;     // word ids (of `words`) sorted by word / by reversed word, len >= wmMinLD1
     // words: doc frequency (word-level IDF) and last doc (affix)
     KeyTable words; std::vector<uint32_t> wordDf; std::vector<int32_t> wordLastDoc; std::vector<float> wordIdf;
+    // WordIdfCache is an OrdinalIgnoreCase dictionary (VectorModel.cs:864-908): words that differ only in alias characters (final sigma / sigma ...) pool their
+    // documents.  Classes with at least one alias member (rare: none in most corpora), keyed by the class representative text; 0 = no entry (df outside (0, N])
+    KeyTable icWords; std::vector<float> icWordIdf;
     std::vector<int64_t> keyToFirst;   // optional reverse map is built lazily by the engine
 };
 
@@ -568,6 +573,32 @@ inline const char* build_index(const DocSource& src, HostIndex& ix, const std::v
             uint64_t lo = wordsCsr.off[k], hi = wordsCsr.off[k + 1];
             ix.wordDf[k] = (uint32_t)(hi - lo); ix.wordLastDoc[k] = hi > lo ? wordsCsr.doc[hi - 1] : -1;
             ix.wordIdf[k] = compute_idf((int)N, (int)(hi - lo));
+        }
+        {   // OrdinalIgnoreCase classes with alias members: document frequency of the CLASS = documents holding any of its words (per document the reference's HashSet is
+            // OrdinalIgnoreCase too: a document counts once)
+            const auto& TT = tables();
+            std::unordered_map<std::u16string, std::vector<uint32_t>> cls;
+            for (uint32_t k = 0; k < W; k++) {
+                uview key = ix.words.key(k); bool alias = false;
+                for (u16 c : key) if (TT.icrep[c] != c) { alias = true; break; }
+                if (!alias) continue;
+                std::u16string F(key.begin(), key.end()); for (auto& c : F) c = (char16_t)TT.icrep[(u16)c];
+                cls[F].push_back(k);
+            }
+            ix.icWords = KeyTable(); ix.icWordIdf.clear();
+            std::vector<std::u16string> order; order.reserve(cls.size());
+            for (auto& kv : cls) order.push_back(kv.first);
+            std::sort(order.begin(), order.end());      // deterministic ids
+            for (auto& F : order) {
+                std::vector<uint32_t> members = cls[F];
+                const int64_t rep = ix.words.find(uview((const u16*)F.data(), F.size())); if (rep >= 0) members.push_back((uint32_t)rep);
+                std::vector<int32_t> docs;
+                for (uint32_t m : members) docs.insert(docs.end(), wordsCsr.doc.begin() + wordsCsr.off[m], wordsCsr.doc.begin() + wordsCsr.off[m + 1]);
+                std::sort(docs.begin(), docs.end()); docs.erase(std::unique(docs.begin(), docs.end()), docs.end());
+                const int df = (int)docs.size();
+                ix.icWords.get_or_add(uview((const u16*)F.data(), F.size()));
+                ix.icWordIdf.push_back((df > 0 && df <= (int)N) ? compute_idf((int)N, df) : 0.f);
+            }
         }
         if (cfg.wordMatcher) {
             for (uint32_t k = 0; k < W; k++) if ((int)ix.words.keyLen[k] >= cfg.wmMinLD1) ix.affixFwd.push_back(k);

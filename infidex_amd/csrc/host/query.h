@@ -562,8 +562,19 @@ inline int32_t prepare_cov_query_t(const HostIndex& ix, uview query, QT& C) {
         if (ix.N > 0 && (int)term.size() >= n)
             for (int j = 0; j + n <= (int)term.size(); j++) { int64_t id = ix.terms.keys.find(term.substr(j, n)); if (id >= 0 && ix.df[id] > 0) { sum += compute_idf(ix.N, ix.df[id]); cnt++; } }
         C.term_idf[i] = cnt > 0 ? sum / (float)cnt : log2f((float)(term.size() + 1));
-        int64_t w = ix.words.find(term);   // WordIdfCache is OrdinalIgnoreCase; both sides are lower-case here
-        C.word_idf[i] = (w >= 0 && ix.wordDf[w] > 0 && (int)ix.wordDf[w] <= ix.N) ? ix.wordIdf[w] : 0.f;
+        // WordIdfCache is OrdinalIgnoreCase and both sides are lower-case here: an exact lookup — unless the word's class has alias members (icWords, keyed by the
+        // class representative: the corpus may hold 'ϑερμος' where the query says 'θερμος', or both)
+        bool classHit = false;
+        const auto& TT = tables(); ustr F(term); bool qAlias = false;
+        for (auto& c : F) { const u16 r = TT.icrep[c]; if (r != c) { qAlias = true; c = r; } }      // the class representative of the query word
+        if (ix.icWords.size()) {
+            const int64_t ci = ix.icWords.find(F);
+            if (ci >= 0) { C.word_idf[i] = ix.icWordIdf[ci]; classHit = true; }
+        }
+        if (!classHit) {      // a class without alias members in the corpus: its only possible word is the representative itself
+            int64_t w = ix.words.find(qAlias ? uview(F) : term);
+            C.word_idf[i] = (w >= 0 && ix.wordDf[w] > 0 && (int)ix.wordDf[w] <= ix.N) ? ix.wordIdf[w] : 0.f;
+        }
     }
     C.has_word_idf = uq.empty() ? 0 : 1;
     C.num_fusion_tokens = (int)fus.size();

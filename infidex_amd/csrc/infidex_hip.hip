@@ -85,6 +85,7 @@ struct infx_index {
     // Turnstile of the full-width phase (k_accumulate .. k_select) between the streams of an index: see infx_search_fused
     std::mutex turnMu; hipEvent_t turnEvent = nullptr;
     bool haveDict = false, haveTrie = false;
+    bool hasAlias = false;            // the corpus text holds one of the 22 OrdinalIgnoreCase alias characters (infx_upload_docs counts them): Stage 2 runs its ALIAS instantiation
 };
 
 template <class Tp> static hipError_t dalloc(infx_index* ix, Tp** p, size_t n) {
@@ -286,6 +287,7 @@ struct infx_stream {
     void* dCovF = nullptr; size_t capCovF = 0;
     int32_t* arDoc = nullptr; float* arScore = nullptr; uint8_t* arCls = nullptr; size_t arCap = 0;
     bool accLayoutBad = false;
+    bool batchAlias = false, longAlias = false;      // ... or the coverage queries of the batch / its long-query table do
     unsigned long long* arMask = nullptr; size_t arMaskCap = 0; int maskWords = 0;     // per-row hit masks of the last accumulate launch
     void* dWideQ = nullptr; size_t capWideQ = 0; uint32_t nWide = 0;                     // queries of the batch with more than 64 reference terms: beyond the masks, never replayed
     uint32_t* arExc = nullptr; uint32_t* exCand = nullptr; infx_hit* exOut = nullptr; size_t exCap = 0;       // tf exception records, candidate lists, replay rows (arena-sized)
@@ -352,17 +354,24 @@ static int s2_waves() { static const int w = [] { const char* e = getenv("INFX_S
 static int s2_pool() { static const int w = [] { const char* e = getenv("INFX_S2_POOL"); int v = e ? atoi(e) : S2_POOL_CHARS; return (v < 0 || v > 32768) ? S2_POOL_CHARS : v; }(); return w; }
 #define S2_GRID(lds) (ncand + S2_THREADS - 1) / S2_THREADS, S2_THREADS, (lds), s->st
 #define S2_FAST_TAIL pool_, (uint16_t*)nullptr, (uint32_t*)nullptr, 0u, (const infx_cov_query_long*)nullptr, s->nLongQ      /* the first launch tells long-query rows apart (and checks their table index) */
-#define S2_LAUNCH_FAST(...) do { const int pool_ = s2_pool(); switch (s2_waves()) { case 2: k_stage2<S2_FASTD, 2><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; case 6: k_stage2<S2_FASTD, 6><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; \
+// AL: the ALIAS instantiation (stage2.hip.inc: OrdinalIgnoreCase sites compare class representatives) — whenever the corpus or the batch's queries hold one of the 22 alias
+// characters; else the plain one (every comparison `==`, exact without them)
+#define S2_AL (s->ix->hasAlias || s->batchAlias)
+#define S2_LAUNCH_FAST(...) do { const int pool_ = s2_pool(); if (S2_AL) { k_stage2<S2_FASTD, 6, false, false, true><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; } \
+                                 switch (s2_waves()) { case 2: k_stage2<S2_FASTD, 2><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; case 6: k_stage2<S2_FASTD, 6><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; \
                                                      case 8: k_stage2<S2_FASTD, 8><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; default: k_stage2<S2_FASTD, 4><<<S2_GRID(pool_ * 2)>>>(__VA_ARGS__, S2_FAST_TAIL); break; } } while (0)
-#define S2_LAUNCH_SLOW(...) k_stage2<S2_MAXD, 4><<<S2_GRID(0)>>>(__VA_ARGS__, 0)
-#define S2_LAUNCH_HUGE(...) k_stage2<S2_HUGE_TOKENS, 1, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16)
+#define S2_LAUNCH_SLOW(...) do { if (S2_AL) k_stage2<S2_MAXD, 4, false, false, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0); else k_stage2<S2_MAXD, 4><<<S2_GRID(0)>>>(__VA_ARGS__, 0); } while (0)
+#define S2_LAUNCH_HUGE(...) do { if (S2_AL) k_stage2<S2_HUGE_TOKENS, 1, true, false, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16); \
+                                 else k_stage2<S2_HUGE_TOKENS, 1, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16); } while (0)
 // rows of long queries (marked by the first launch): documents up to S2_MAXD words, then the rest through the global-workspace pass; nothing is launched for a batch without long queries.
 // The table is consumed: the next Stage-2 call starts without one.
 #define S2_LAUNCH_LONGQ(...) do { if (s->nLongQ) { \
-    k_stage2<S2_MAXD, 2, false, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)nullptr, (uint32_t*)nullptr, 0u, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
+    if (S2_AL) k_stage2<S2_MAXD, 2, false, true, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)nullptr, (uint32_t*)nullptr, 0u, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
+    else k_stage2<S2_MAXD, 2, false, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)nullptr, (uint32_t*)nullptr, 0u, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
     (void)hipMemsetAsync(s->dHugeCnt, 0, 4, s->st);      /* the long-query rows get the whole token-table pool, not what the ordinary rows' pool pass left of it */ \
-    k_stage2<S2_HUGE_TOKENS, 1, true, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
-    s->nLongQ = 0; } } while (0)
+    if (S2_AL) k_stage2<S2_HUGE_TOKENS, 1, true, true, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
+    else k_stage2<S2_HUGE_TOKENS, 1, true, true><<<S2_GRID(0)>>>(__VA_ARGS__, 0, (uint16_t*)s->dHugeWs, (uint32_t*)s->dHugeCnt, (uint32_t)S2_HUGE_POOL_U16, (const infx_cov_query_long*)s->dCovQL, s->nLongQ); \
+    s->nLongQ = 0; s->longAlias = false; } } while (0)
 static int32_t s2_huge_ready(infx_stream* s);
 
 // ---- host <-> device transfers through pinned staging -------------------------------------------------------------------
@@ -776,7 +785,13 @@ int32_t infx_upload_docs(infx_index* ix, uint32_t N, const float* doc_len, float
         HIPCHK(dalloc(ix, &dTO, (size_t)N + 1)); HIPCHK(dalloc(ix, &dTx, (size_t)tot));
         HIPCHK(hipMemcpy(dTO, text_offs, ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dTx, text, (size_t)tot * 2, hipMemcpyHostToDevice));
-        if (tot) { k_fold_ic<<<(unsigned)std::min<uint64_t>((tot + 255) / 256, 65536), 256>>>(dTx, (unsigned long long)tot); HIPCHK(hipGetLastError()); }      // OrdinalIgnoreCase fold (stage2.hip.inc)
+        if (tot) {      // OrdinalIgnoreCase alias characters of the corpus (stage2.hip.inc): none in most corpora — then every Stage-2 comparison is `==`
+            unsigned long long* dCnt = nullptr; unsigned long long hCnt = 0;
+            HIPCHK(hipMalloc((void**)&dCnt, 8)); HIPCHK(hipMemset(dCnt, 0, 8));
+            k_count_alias<<<(unsigned)std::min<uint64_t>((tot + 255) / 256, 65536), 256>>>(dTx, (unsigned long long)tot, dCnt);
+            HIPCHK(hipGetLastError()); HIPCHK(hipMemcpy(&hCnt, dCnt, 8, hipMemcpyDeviceToHost)); hipFree(dCnt);
+            ix->hasAlias = hCnt != 0;
+        }
     }
     if (ix->cfg.range_docs == 0) {   // default: wide ranges for large shards (fewer, longer per-range posting slices; measured best at 10M docs)
         int R = N >= (4u << 20) ? 8192 : N >= (1u << 20) ? 4096 : N >= (1u << 18) ? 2048 : 1024;
@@ -1286,8 +1301,8 @@ int32_t infx_stage2_long_queries(infx_stream* s, uint32_t n, const infx_cov_quer
     }
     GROW(s->dCovQL, s->capCovQL, (size_t)n * sizeof(infx_cov_query_long));
     UP(s->dCovQL, q, (size_t)n * sizeof(infx_cov_query_long));
-    k_fold_ic_longq<<<n, WAVE, 0, s->st>>>((infx_cov_query_long*)s->dCovQL, n);
-    HIPCHK(hipGetLastError());
+    s->longAlias = false;
+    for (uint32_t i = 0; i < n && !s->longAlias; i++) for (int32_t k = 0; k < q[i].text_len; k++) if (s2_host_is_alias(q[i].text[k])) { s->longAlias = true; break; }
     s->nLongQ = n;
     return INFX_OK;
 }
@@ -1313,7 +1328,8 @@ int32_t infx_stage2_batch(infx_stream* s, uint32_t nq, const infx_cov_query* q, 
     GROW(s->dCovO, s->capCovO, (size_t)ncand * sizeof(infx_cov_out));
     if (feat_out) GROW(s->dCovF, s->capCovF, (size_t)ncand * INFX_NFEAT * 4);
     UP(s->dCovQ, q, (size_t)nq * sizeof(infx_cov_query));
-    if (nq) k_fold_ic_queries<<<nq, WAVE, 0, s->st>>>((infx_cov_query*)s->dCovQ, nq);
+    s->batchAlias = s->longAlias;
+    for (uint32_t i = 0; i < nq && !s->batchAlias; i++) if (q[i].reserved == 0) for (int32_t k = 0; k < q[i].text_len && k < (int32_t)INFX_MAX_QUERY_CHARS; k++) if (s2_host_is_alias(q[i].text[k])) { s->batchAlias = true; break; }
     UP(s->dCovC, cand, (size_t)ncand * sizeof(infx_cov_cand));
     HIPCHK(hipEventRecord(s->evC0, s->st));
     S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq,
@@ -1505,7 +1521,7 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, 
         if (shardNext) GROW(s->dNext, s->capNext, (size_t)nd * 4);       // document shards: no local flags — the cut is global (k_gflag)
         k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr,
                                                 shardNext ? (float*)s->dNext : nullptr, select_order(s, nd));
-        if (markTurn) { HIPCHK(hipEventRecord(s->evTurn, s->st)); markTurn = false; }      // the wide phase of this batch ends here
+        if (markTurn) { HIPCHK(hipEventRecord(s->evTurn, s->st)); markTurn = false; }      // the wide phase of this batch ends here (round 6 measured the event in FRONT of k_select — the next batch's accumulation beside this k_select's tail of giant queries: 93.7 / 94.2 k against 93.8 / 94.3 k queries/s, nothing)
         if (exact) { int32_t rc_ = select_wide_queries(s, ar, depth); if (rc_) return rc_; }
         if (exact) { int32_t rc_ = enqueue_exact(s, nd, depth); if (rc_) return rc_; }
     }
@@ -1553,6 +1569,8 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
     UP(s->dFLists, lists, (size_t)nlists * sizeof(infx_wm_list));
     UP(s->dFOwned, owned, (size_t)owned_n * 4);
     UP(s->dCovQ, cq, (size_t)nq * sizeof(infx_cov_query));
+    s->batchAlias = s->longAlias;      // (host scan of the query texts: ~20 characters per query)
+    for (uint32_t i = 0; i < nq && !s->batchAlias; i++) if (cq[i].reserved == 0) for (int32_t k = 0; k < cq[i].text_len && k < (int32_t)INFX_MAX_QUERY_CHARS; k++) if (s2_host_is_alias(cq[i].text[k])) { s->batchAlias = true; break; }
     HIPCHK(hipMemsetAsync(s->dCovO, 0, (size_t)ncand * sizeof(infx_cov_out), s->st));
     HIPCHK(hipEventRecord(s->evP0, s->st));
     if (wmDev) {
@@ -1569,7 +1587,6 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evP1, s->st));
-    if (nq) k_fold_ic_queries<<<nq, WAVE, 0, s->st>>>((infx_cov_query*)s->dCovQ, nq);      // after k_wm: the dictionary lookups take the lower-cased words as they are
     HIPCHK(hipEventRecord(s->evC0, s->st));
     S2_LAUNCH_FAST(ix->d, (const infx_cov_query*)s->dCovQ, nq, (const infx_cov_cand*)s->dCovC, ncand,
                                                                                  (infx_cov_out*)s->dCovO, want_debug ? (int32_t*)s->dCovF : nullptr, 1, 0, (const int32_t*)s->dFPairs);

@@ -452,18 +452,33 @@ def test_scripts_beyond_latin1_full_parity():
 
 
 def test_ordinal_ignore_case_aliases():
-    """Where an alias character meets its base letter: OrdinalIgnoreCase compares ToUpperInvariant images, so a document word 'λογοσκοπος' starts with the query
-    word 'λογος' (final sigma and sigma share the capital), 'ſtraße' equals 'straße', 'µm' equals 'μm'.  The device text and query are folded for exactly that
-    (k_fold_ic); the returned DOCUMENTS must be the oracle's.  (Scores may differ by the reference's few ToLowerInvariant comparison sites, which see alias and
-    base as different characters: not compared here.)"""
+    """Where an alias character meets its base letter.  OrdinalIgnoreCase compares ToUpperInvariant images, so a document word 'λογοσκοπος' starts with the query word
+    'λογος' (final sigma and sigma share the capital), 'ſtraße' equals 'straße', 'µm' equals 'μm' — while the reference's ToLowerInvariant / ordinal sites (the LCS,
+    the transposition scan of CalculateDamerau, FusionSignalComputer.cs:191-228, 427, 457-550, FuzzyWordMatcher.cs:110) see alias and base as DIFFERENT characters.
+    Round 6: Stage 2 runs its ALIAS instantiation for such corpora / queries and compares per site as the reference does: returned documents, final scores and every
+    integer feature equal the oracle's (rounds 4-5 folded the texts and only the documents were compared)."""
     docs = [(1, "λογοσκοπος αλφα"), (2, "λογος βητα"), (3, "ſtraße lang"), (4, "straße kurz"), (5, "10 µm filter"), (6, "10 μm sieve"), (7, "unrelated text here"),
-            (8, "ΛΟΓΟΣ ΚΕΦΑΛΑΙΑ"), (9, "ϑερμος ϕως"), (10, "θερμος φως")]
+            (8, "ΛΟΓΟΣ ΚΕΦΑΛΑΙΑ"), (9, "ϑερμος ϕως"), (10, "θερμος φως"), (11, "λογοσ λογος λογοι"), (12, "κοσμος κοσμοσ κοςμος"), (13, "οδυσσευς οδυσσευσ ταξιδι")]
     e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
     o = O.OracleEngine.create_default(); o.index(docs)
-    for q in ["λογος", "λογοσ", "straße", "ſtraße", "µm filter", "μm sieve", "θερμος", "ϑερμος φως", "ΛΟΓΟΣ"]:
+    queries = ["λογος", "λογοσ", "straße", "ſtraße", "µm filter", "μm sieve", "θερμος", "ϑερμος φως", "ΛΟΓΟΣ", "κοσμος", "κοσμοσ", "οδυσσευς ταξιδι", "λογοσ λογοι", "κοςμος κοσμος"]
+    for q in queries:
         got = [x.document_id for x in e.search(q, 10).records]
         want = o.search(q, 10)["keys"]
         assert sorted(got) == sorted(want), (q, got, want)
+    st = compare_batch(e, o, queries, 10)
+    assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0 and st["order_unclassified"] == 0, st
+
+
+def test_alias_characters_in_the_queries_only():
+    """The corpus holds no alias character (the plain Stage-2 instantiation would do) but a query does: the batch runs the ALIAS instantiation — 'λογος' against a
+    document 'λογοσ' differs at the lower-case sites.  Rows, scores, features equal the oracle's; a batch without such a query runs the plain instantiation again."""
+    docs = [(1, "λογοσ βητα"), (2, "κοσμοσ αλφα"), (3, "λογοσκοποσ γαμμα"), (4, "plain latin text"), (5, "ταξιδι κοσμοσ λογοσ")]
+    e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+    o = O.OracleEngine.create_default(); o.index(docs)
+    for queries in (["λογος", "κοσμος λογος", "plain text", "λογοσκοπος"], ["λογοσ", "plain latin", "κοσμοσ ταξιδι"]):
+        st = compare_batch(e, o, queries, 10)
+        assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0 and st["order_unclassified"] == 0, (queries, st)
 
 
 ASTRAL_DOCS = [(1, "\U0001F50Dab zeta"), (2, "\U0001F50Eab yotta"), (3, "plain \U0001F50Dab"), (4, "x\U0001F50D \U0001F50Ex \U0001F50Dab"), (5, "\U0001F50D"),
