@@ -448,6 +448,8 @@ def main():
         # what every rank issued through the native driver (set-up + warm-up + timed batches): W ranks with equal counts = RCCL saw W ranks in step
         cs = searcher.coll_stats()
         cs["batches"] = len(searcher.sessions) + nsteps
+        cs["transport"] = ("gloo host buffers (in-library RCCL could not be brought up: fallback)" if getattr(searcher.comm, "rccl_fallback", False)
+                           else ("RCCL inside the library, HBM buffers, on the sessions' streams" if dist is not None and dist.get_backend() == "nccl" else "torch.distributed callbacks (gloo), host buffers"))
         # the plan exchange: queries of this rank's last batch planned from exchanged plans (own slice + peers') / imported from peers (W = 1: nothing to exchange)
         px = searcher.plan_exchange_stats()
         cs["plan_exchange"] = {"on": bool(searcher.partition_planning), "queries_planned_from_exchange": px[0], "of_them_imported_from_peers": px[1]}
