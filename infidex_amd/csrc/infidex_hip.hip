@@ -503,9 +503,10 @@ static int acc_stripe() { static const int v = [] { const char* e = getenv("INFX
 // LDS starts at address 0.  Checked once per instantiation against the code object; a violation fails the search loudly.
 template <int R> static bool acc_lds_layout_ok() {
     static const bool ok = [] {
-        hipFuncAttributes a1{}, a2{};
-        if (hipFuncGetAttributes(&a1, (const void*)k_accumulate<R, 1>) != hipSuccess || hipFuncGetAttributes(&a2, (const void*)k_accumulate<R, 2>) != hipSuccess) return false;
-        return a1.sharedSizeBytes == 0 && a2.sharedSizeBytes == 0;
+        hipFuncAttributes a1{}, a2{}, a4{};
+        if (hipFuncGetAttributes(&a1, (const void*)k_accumulate<R, 1>) != hipSuccess || hipFuncGetAttributes(&a2, (const void*)k_accumulate<R, 2>) != hipSuccess ||
+            hipFuncGetAttributes(&a4, (const void*)k_accumulate<R, 4>) != hipSuccess) return false;
+        return a1.sharedSizeBytes == 0 && a2.sharedSizeBytes == 0 && a4.sharedSizeBytes == 0;
     }();
     return ok;
 }
@@ -529,21 +530,17 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
         const int maxTl = (std::min(64, std::max(1, maxT)) + 3) & ~3;
         static const int dbgS = [] { const char* e = getenv("INFX_ACCS_SKIP"); return e ? atoi(e) : 0; }();      // kernel ablation for profiling only
         const size_t ldsS = (sw + 64 + 4) * 4 + INFX_NCLASS * 4 + WAVE * 2 + WAVE * 12 + (size_t)WAVE * maxTl + (size_t)64 * maxTl;      // padded bitmap (one pad word per lane) | class histogram | slot table | slice table | hit matrix | slice samples
-        if (ar.maskWords == 2)
-            k_accumulate_sparse<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
-                                                                                         (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, (uint8_t*)s->dDense, (uint32_t)sparseT, nStripes, maxTl, dbgS);
-        else
-            k_accumulate_sparse<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra,
-                                                                                         (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, (uint8_t*)s->dDense, (uint32_t)sparseT, nStripes, maxTl, dbgS);
+#define ACCS_LAUNCH(MW_) k_accumulate_sparse<R, MW_><<<dim3((unsigned)blocks), dim3(WAVE), ldsS, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra, \
+            (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, stripe, useGrp, (uint8_t*)s->dDense, (uint32_t)sparseT, nStripes, maxTl, dbgS)
+        if (ar.maskWords == 4) ACCS_LAUNCH(4); else if (ar.maskWords == 2) ACCS_LAUNCH(2); else ACCS_LAUNCH(1);
+#undef ACCS_LAUNCH
         dense = (const uint8_t*)s->dDense;
     }
     const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
-    if (ar.maskWords == 2)
-        k_accumulate<R, 2><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nStripes);
-    else
-        k_accumulate<R, 1><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms,
-                                                                           (const int32_t*)s->dExtra, (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nStripes);
+#define ACC_LAUNCH(MW_) k_accumulate<R, MW_><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra, \
+        (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nStripes)
+    if (ar.maskWords == 4) ACC_LAUNCH(4); else if (ar.maskWords == 2) ACC_LAUNCH(2); else ACC_LAUNCH(1);
+#undef ACC_LAUNCH
     if (dbgSkip & 8) { unsigned long long h[4] = {0, 0, 0, 0}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 32, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 32);
         fprintf(stderr, "[infx] k_accumulate stats: %llu ranges with candidates (%llu blocks), %.2f rounds/range, %.1f candidates/range\n", h[0], (unsigned long long)blocks, h[0] ? (double)h[1] / h[0] : 0.0, h[0] ? (double)h[2] / h[0] : 0.0); }
 }
@@ -566,13 +563,12 @@ static int ex_heap_in_regs(const infx_index* ix, int depth) {
     const long long total = std::max<long long>(ix->d.totalDocs, (long long)ix->d.docBase + ix->d.N);
     return (!off && depth <= EXS_MAXDEPTH && total < (1ll << 30)) ? 1 : 0;
 }
-__global__ void k_clear_flags(uint32_t* __restrict__ flags, const uint32_t* __restrict__ list, uint32_t n) { for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) flags[list[i]] = 0u; }
-// After the batch's k_select (with replay flags): the queries beyond the hit masks are selected once more WITHOUT flags — k_select then cuts an over-long
-// plateau by doc id itself instead of leaving it to the replay — and their flags are cleared, so the replay kernels skip them.
-static int32_t select_wide_queries(infx_stream* s, Arena ar, int depth) {
-    if (!s->nWide) return INFX_OK;
-    k_select<<<s->nWide, SEL_THREADS, 0, s->st>>>(ar, s->ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, nullptr, nullptr, nullptr, (const uint32_t*)s->dWideQ);
-    k_clear_flags<<<1, 64, 0, s->st>>>((uint32_t*)s->dExactFlag, (const uint32_t*)s->dWideQ, s->nWide);
+// After the batch's k_select (with replay flags): a flagged query beyond two mask words (65 .. 128 reference terms) goes to the sequential replay (k_exact1 reads
+// its four-word masks from the arena; the parallel replay's kernels keep two words in registers) — flag 1 -> 2, what k_ex_theta / k_ex_heap write for a query they hand over.
+__global__ void k_mark_wide(uint32_t* __restrict__ flags, const uint32_t* __restrict__ list, uint32_t n) { for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) if (flags[list[i]] == 1u) flags[list[i]] = 2u; }
+static int32_t mark_wide_queries(infx_stream* s, int depth) {
+    if (!s->nWide || exact_slow_only() || depth > EXS_MAXDEPTH) return INFX_OK;      // (no parallel replay: k_exact1 takes every flagged query as it is)
+    k_mark_wide<<<1, 64, 0, s->st>>>((uint32_t*)s->dExactFlag, (const uint32_t*)s->dWideQ, s->nWide);
     HIPCHK(hipGetLastError());
     return INFX_OK;
 }
@@ -616,7 +612,7 @@ static int32_t launch_scan_and_chunks(infx_stream* s, uint32_t nq, Arena ar, ExB
 }
 static int32_t exact1_lds_ready(infx_index* ix, int MW, size_t* ldsOut) {
     const int depthCap = ix->cfg.max_depth;
-    const size_t lds1 = (size_t)(EX_CHUNK + EX_THREADS) * MW * 8 + (size_t)(EX_CHUNK + EX_THREADS) * 4 + (size_t)EX_CHUNK * 4 + (size_t)depthCap * 8 +
+    const size_t lds1 = (size_t)(EX_CHUNK + EX_THREADS) * (MW <= 2 ? MW : 1) * 8 + (size_t)(EX_CHUNK + EX_THREADS) * 4 + (size_t)EX_CHUNK * 4 + (size_t)depthCap * 8 +
                         (INFX_MAX_QUERY_TERMS + 1) * 4 + 130 * 4 + 129 * 4 + 8 * 4 + (size_t)EX_CHUNK * 2 + 64;
     static std::mutex mu; static size_t attr1 = 0;
     { std::lock_guard<std::mutex> lk(mu);
@@ -1162,10 +1158,12 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
             return fail(INFX_ENOMEM, "arena allocation failed%s");
         s->arCap = n;
     }
-    // per-row hit masks (2 bits per reference term) for the exact Stage-1 replay, as wide as the batch's queries of <= 64 terms need.  A query with more terms
-    // (a very long query: words + n-grams, up to 128) has no complete masks and is never replayed — k_select finishes it (select_wide_queries), k_gflag passes it
-    // over — WITHOUT taking the replay away from the other queries of its batch (it used to: one such query switched the masks off for all).
-    s->maskWords = !exact_enabled(ix) || wideQ.size() == nq ? 0 : (maxRefNarrow <= 32 ? 1 : 2);
+    // per-row hit masks (2 bits per reference term) for the exact Stage-1 replay, as wide as the batch's queries need: one or two 64-bit words for queries of <= 64
+    // terms.  A query with more terms (a very long query: words + n-grams, up to 128 = VectorModel.cs:381's cap) takes FOUR words for the rows of its whole batch
+    // (round 6; rare: the masks of such a batch cost twice the bytes) and is replayed by the sequential kernel, which reads the masks from the arena (k_mark_wide,
+    // k_exact1).  Document shards keep two words and the first-pass cut for such a query (k_gflag passes it over): the sharded replay's kernels hold two words.
+    const bool wideExact = !wideQ.empty() && exact_enabled(ix) && ix->nranks == 1 && ix->d.docBase == 0;
+    s->maskWords = !exact_enabled(ix) || (!wideExact && wideQ.size() == nq) ? 0 : (wideExact ? 4 : (maxRefNarrow <= 32 ? 1 : 2));
     s->nWide = (uint32_t)wideQ.size();
     if (s->nWide) { GROW(s->dWideQ, s->capWideQ, wideQ.size() * 4); UP(s->dWideQ, wideQ.data(), wideQ.size() * 4); }
     if (s->maskWords && s->arCap * (size_t)s->maskWords > s->arMaskCap) {
@@ -1263,7 +1261,7 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     const bool exact = exact_possible(s);
     if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
     k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr, nullptr, select_order(s, nq));
-    if (exact) { int32_t rc_ = select_wide_queries(s, ar, maxDepth); if (rc_) return rc_; }
+    if (exact) { int32_t rc_ = mark_wide_queries(s, ix->cfg.max_depth); if (rc_) return rc_; }
     if (exact) { int32_t rc_ = enqueue_exact(s, nq, maxDepth); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evS1, s->st));
@@ -1522,7 +1520,7 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, 
         k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr,
                                                 shardNext ? (float*)s->dNext : nullptr, select_order(s, nd));
         if (markTurn) { HIPCHK(hipEventRecord(s->evTurn, s->st)); markTurn = false; }      // the wide phase of this batch ends here (round 6 measured the event in FRONT of k_select — the next batch's accumulation beside this k_select's tail of giant queries: 93.7 / 94.2 k against 93.8 / 94.3 k queries/s, nothing)
-        if (exact) { int32_t rc_ = select_wide_queries(s, ar, depth); if (rc_) return rc_; }
+        if (exact) { int32_t rc_ = mark_wide_queries(s, ix->cfg.max_depth); if (rc_) return rc_; }
         if (exact) { int32_t rc_ = enqueue_exact(s, nd, depth); if (rc_) return rc_; }
     }
     if (markTurn) HIPCHK(hipEventRecord(s->evTurn, s->st));

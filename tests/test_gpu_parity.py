@@ -327,6 +327,46 @@ def test_long_queries_take_the_long_query_launches():
     assert [x.document_id for x in r[3].records] == o.search(q40, 5)["keys"]
 
 
+def test_queries_beyond_64_reference_terms_take_the_exact_cut():
+    """A query of 40 words carries more than 64 reference terms (words + n-grams, up to 128: VectorModel.cs:381): its rows take four mask words and the sequential
+    replay (k_mark_wide, k_exact1 reading the masks from the arena).  The corpus repeats every text 2 .. 30 times, so the Stage-1 scores form plateaus across
+    the cuts at depths 40, 7 and 3: with the first-pass cut (k_select by document id, rounds 2-5) the SET differs from the oracle's heap at some of them; with the replay
+    it is the oracle's for every query — narrow queries of the same batch (parallel replay over the first two words of four) included."""
+    import random
+    rng = random.Random(23)
+    vocab = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet", "kilo", "lima", "mike",
+             "november", "oscar", "papa", "quebec", "romeo", "sierra", "tango", "uniform", "victor", "whiskey", "xray", "yankee", "zulu"]
+    texts = []
+    for i in range(160):
+        n = rng.choice([3, 5, 8, 12, 20, 40])
+        texts.append(" ".join(rng.choice(vocab) + (str(rng.randrange(12)) if rng.random() < 0.4 else "") for _ in range(n)))
+    docs = []
+    for t in texts:
+        for _ in range(rng.choice([2, 3, 5, 11, 30])): docs.append((len(docs), t))
+    rng.shuffle(docs); docs = [(i, t) for i, (_, t) in enumerate(docs)]
+    e = gpu_engine(); e.index_documents([Document(k, t) for k, t in docs])
+    o = O.OracleEngine.create_default(); o.index(docs)
+    q40 = " ".join(vocab[i % 26] + (str(i % 12) if i % 3 == 0 else "") for i in range(40))
+    q60 = " ".join(vocab[(7 * i) % 26] + (str(i % 12) if i % 2 else "") for i in range(60))
+    wide = [q40, q60, q40 + " zulu7", " ".join(texts[i] for i in (3, 9, 27))]
+    qs = ["alpha bravo", wide[0], "charlie delta echo", wide[1], "golf hotel india juliet kilo lima mike november", texts[5], wide[2], wide[3]]
+    for depth in (40, 7, 3):
+        st = compare_batch(e, o, qs, 10, depth=depth)
+        assert st["set_mismatch"] == 0 and st["feat_mismatch"] == 0 and st["order_unclassified"] == 0 and st["s1_boundary"] == 0, (depth, st)
+        assert st["s1_bitexact"] == len(qs), (depth, st)
+    # the test bites: without the replay (the first-pass cut by document id, what such queries got before) some of these cuts are not the oracle's ...
+    u = gpu_engine(exact_replay=False); u.index_documents([Document(k, t) for k, t in docs])
+    bites = sum(compare_batch(u, o, wide, 10, depth=d, check_features=False)["s1_boundary"] for d in (40, 7, 3))
+    assert bites > 0
+    # ... and every wide query alone in its batch (no narrow query: four mask words for nobody else) is replayed and right
+    replays = 0
+    for q in wide:
+        st = compare_batch(e, o, [q], 10, depth=7)
+        assert st["s1_boundary"] == 0 and st["s1_bitexact"] == 1 and st["set_mismatch"] == 0, st
+        replays += e.last_timings()["exact_replays"]
+    assert replays >= 2, replays
+
+
 def test_long_tokens_have_no_length_limit():
     """Tokens far longer than any fixed cost row: the Levenshtein band (k_stage2) lives in registers, so 70-150 character words in documents
     and queries (exact, one typo, prefix, joined) are scored like the reference does — no envelope on the token length any more."""
