@@ -518,7 +518,7 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
     (void)maxRef;
     if (!acc_lds_layout_ok<R>()) { s->accLayoutBad = true; return; }
     static const int dbgSkip = [] { const char* e = getenv("INFX_ACC_SKIP"); return e ? atoi(e) : 0; }();     // kernel ablation for profiling only
-    const int sparseT = acc_sparse_t();
+    const int sparseT = s->ix->hPostOff.empty() || s->ix->hPostOff.back() + 4 <= 0xFFFFFFF0ull ? acc_sparse_t() : 0;      // (k_accumulate_sparse indexes a shard's postings with 32 bits)
     const int stripe = sparseT > 0 ? std::max(1, std::min(4, 65536 / R)) : acc_stripe();      // (the two kernels split the same stripes: a power of two)
     const int nStripes = (s->ix->d.nRanges + stripe - 1) / stripe;
     const uint64_t blocks = (uint64_t)nq * 8u * ((nStripes + 7) / 8);     // stripes rounded up to whole groups of 8 (one per XCD)
