@@ -293,6 +293,7 @@ struct infx_stream {
     uint32_t* arExc = nullptr; uint32_t* exCand = nullptr; infx_hit* exOut = nullptr; size_t exCap = 0;       // tf exception records, candidate lists, replay rows (arena-sized)
     void* exChunks = nullptr; size_t capExChunks = 0; void* exQueries = nullptr; size_t capExQueries = 0; void* exTasks = nullptr; size_t capExTasks = 0; uint32_t* exCounters = nullptr;
     void* dSelOrder = nullptr; size_t capSelOrder = 0;        // k_select_order: the batch's queries by row count, descending
+    void* dSelG = nullptr; size_t capSelG = 0;                // k_selg_hist / k_selg_gather: global histograms, key lists and flags of the batch's largest queries
     void* exContEnd = nullptr; size_t capExContEnd = 0;      // k_ex_cand: candidates up to the end of every (query, container)
     uint32_t exChunkCap = 0; size_t arBound = 0;
     void* dDir = nullptr; size_t capDir = 0;
@@ -552,6 +553,22 @@ static const uint32_t* select_order(infx_stream* s, uint32_t nq) {
     if (grow(s, &s->dSelOrder, &s->capSelOrder, (size_t)nq * 4)) return nullptr;
     k_select_order<<<1, 1024, 0, s->st>>>((const uint32_t*)s->dBlockOutHi, nq, (uint32_t*)s->dSelOrder);
     return (const uint32_t*)s->dSelOrder;
+}
+// The largest queries of the batch swept by many workgroups in front of k_select (k_selg_hist / k_selg_gather, stage1.hip.inc).  INFX_SEL_GIANT_MIN: rows from which a
+// query is one (default 65536; 0: off — k_select sweeps every query itself).  Needs the longest-first order (its first SELG_MAX entries are the candidates).
+static SelGiant select_giants(infx_stream* s, Arena ar, uint32_t nq, const uint32_t* order) {
+    static const uint32_t minRows = [] { const char* e = getenv("INFX_SEL_GIANT_MIN"); return e ? (uint32_t)std::max(0, atoi(e)) : 65536u; }();
+    SelGiant G{}; if (!order || !minRows) return G;
+    const size_t head = (size_t)SELG_MAX * 2 * 4096 * 4 + (size_t)SELG_MAX * 4 * 5, total = head + (size_t)SELG_MAX * SEL_CAP * 8;
+    if (grow(s, &s->dSelG, &s->capSelG, total)) return G;
+    hipMemsetAsync(s->dSelG, 0, head, s->st);
+    G.hist = (uint32_t*)s->dSelG; G.count = G.hist + (size_t)SELG_MAX * 2 * 4096; G.left = G.count + SELG_MAX; G.mode = G.left + SELG_MAX; G.cut = G.mode + SELG_MAX; G.shift = G.cut + SELG_MAX;
+    G.keys = (unsigned long long*)((char*)s->dSelG + head); G.minRows = minRows;
+    const dim3 grid(SELG_PARTS, std::min<uint32_t>(SELG_MAX, nq));
+    k_selg_hist<<<grid, SEL_THREADS, 0, s->st>>>(ar, (const SelRule*)s->dRules, order, nq, G);
+    k_selg_cut<<<grid.y, 256, 0, s->st>>>(ar, (const SelRule*)s->dRules, order, nq, G);
+    k_selg_gather<<<grid, SEL_THREADS, 0, s->st>>>(ar, (const SelRule*)s->dRules, order, nq, G);
+    return G;
 }
 // k_exact1 behind k_select: unsharded indexes only (the reference's chunking follows GLOBAL 65 536-id containers and its heap is sequential
 // over the whole corpus; document shards keep k_select's deterministic (score, doc id) cut)
@@ -1031,7 +1048,7 @@ void infx_stream_destroy(infx_stream* s) {
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
                   s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters, s->exContEnd, s->dExProf, s->dSelOrder,
-                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount, s->dDense};
+                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount, s->dDense, s->dSelG};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
     for (void* p : s->parked) hipFree(p);
@@ -1260,7 +1277,9 @@ int32_t infx_stage1_select(infx_stream* s, uint32_t nq, const infx_counts* count
     HIPCHK(hipEventRecord(s->evS0, s->st));
     const bool exact = exact_possible(s);
     if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
-    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr, nullptr, select_order(s, nq));
+    const uint32_t* selOrd = select_order(s, nq);
+    k_select<<<nq, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, maxDepth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr, nullptr, selOrd,
+                                            select_giants(s, ar, nq, selOrd));
     if (exact) { int32_t rc_ = mark_wide_queries(s, ix->cfg.max_depth); if (rc_) return rc_; }
     if (exact) { int32_t rc_ = enqueue_exact(s, nq, maxDepth); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
@@ -1517,8 +1536,31 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, 
         const bool exact = !shardNext && exact_possible(s);
         if (exact) HIPCHK(hipMemsetAsync(s->dExactStat + 4, 0, 16, s->st));
         if (shardNext) GROW(s->dNext, s->capNext, (size_t)nd * 4);       // document shards: no local flags — the cut is global (k_gflag)
+#ifdef SEL_PROF
+        static unsigned long long* dProf = nullptr; static int profCalls = 0;
+        if (getenv("INFX_SEL_PROF") && nd >= 500) { if (!dProf) { hipMalloc((void**)&dProf, 4096 * 64); hipMemcpyToSymbol(HIP_SYMBOL(g_selProf), &dProf, sizeof(dProf)); } hipMemsetAsync(dProf, 0, (size_t)nd * 64, s->st); }
+#endif
+        const uint32_t* selOrd = select_order(s, nd);
+        const SelGiant selG = select_giants(s, ar, nd, selOrd);
         k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr,
-                                                shardNext ? (float*)s->dNext : nullptr, select_order(s, nd));
+                                                shardNext ? (float*)s->dNext : nullptr, selOrd, selG);
+#ifdef SEL_PROF
+        if (dProf && nd >= 500 && ++profCalls == 6) {
+            hipStreamSynchronize(s->st);
+            std::vector<unsigned long long> h((size_t)nd * 8); hipMemcpy(h.data(), dProf, h.size() * 8, hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull, t5 = 0; for (uint32_t q = 0; q < nd; q++) { t0 = std::min(t0, h[q * 8]); t5 = std::max(t5, h[q * 8 + 5]); }
+            fprintf(stderr, "[selprof] span %.1f us (100 MHz ticks)\n", (t5 - t0) / 100.0);
+            std::vector<uint32_t> ord(nd); for (uint32_t q = 0; q < nd; q++) ord[q] = q;
+            std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return h[a * 8 + 5] - h[a * 8] > h[b * 8 + 5] - h[b * 8]; });
+            auto us = [&](uint32_t q, int a, int b) { const unsigned long long x = h[q * 8 + a], y = h[q * 8 + b]; return (x && y) ? (double)(y - x) / 100.0 : -1.0; };
+            for (int i = 0; i < 12; i++) { const uint32_t q = ord[i]; fprintf(stderr, "[selprof] #%d q %u rows %llu n %llu: start %.1f total %.1f | hist1 %.1f hist2 %.1f gather %.1f sort %.1f write %.1f (0->3 %.1f)\n", i, q, h[q * 8 + 6], h[q * 8 + 7], (h[q * 8] - t0) / 100.0, us(q, 0, 5), us(q, 0, 1), us(q, 1, 2), us(q, 2, 3), us(q, 3, 4), us(q, 4, 5), us(q, 0, 3)); }
+            for (int pct : {50, 90, 99}) { const uint32_t q = ord[(size_t)nd * (100 - pct) / 100]; fprintf(stderr, "[selprof] p%d q %u rows %llu n %llu: start %.1f total %.1f | hist1 %.1f hist2 %.1f gather %.1f sort %.1f write %.1f (0->3 %.1f)\n", pct, q, h[q * 8 + 6], h[q * 8 + 7], (h[q * 8] - t0) / 100.0, us(q, 0, 5), us(q, 0, 1), us(q, 1, 2), us(q, 2, 3), us(q, 3, 4), us(q, 4, 5), us(q, 0, 3)); }
+            std::vector<unsigned long long> st(nd), en(nd); for (uint32_t q = 0; q < nd; q++) { st[q] = h[q * 8] - t0; en[q] = h[q * 8 + 5] - t0; }
+            std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+            fprintf(stderr, "[selprof] starts: p10 %.1f p50 %.1f p90 %.1f max %.1f us; ends: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us\n", st[nd / 10] / 100.0, st[nd / 2] / 100.0, st[nd * 9 / 10] / 100.0, st[nd - 1] / 100.0,
+                    en[nd / 10] / 100.0, en[nd / 2] / 100.0, en[nd * 9 / 10] / 100.0, en[nd * 99 / 100] / 100.0, en[nd - 1] / 100.0);
+        }
+#endif
         if (markTurn) { HIPCHK(hipEventRecord(s->evTurn, s->st)); markTurn = false; }      // the wide phase of this batch ends here (round 6 measured the event in FRONT of k_select — the next batch's accumulation beside this k_select's tail of giant queries: 93.7 / 94.2 k against 93.8 / 94.3 k queries/s, nothing)
         if (exact) { int32_t rc_ = mark_wide_queries(s, ix->cfg.max_depth); if (rc_) return rc_; }
         if (exact) { int32_t rc_ = enqueue_exact(s, nd, depth); if (rc_) return rc_; }

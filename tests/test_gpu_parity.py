@@ -563,8 +563,8 @@ def test_accumulate_schedules_agree_bit_for_bit(tmp_path):
     """Stage-1 accumulation is the same arithmetic in the same order whichever kernel takes a (query, stripe) pair and however the blocks are scheduled: the sparse
     kernel (k_accumulate_sparse: candidates look their postings up) for stripes of <= INFX_ACC_SPARSE_T candidates and the streaming kernel (k_accumulate: byte scatter
     + probe per (list, range)) for the rest, or the streaming kernel alone with the XCD-aware block map or the query-fastest one (INFX_ACC_SKIP=32) and stripes of
-    1 / 2 / 8 doc ranges per wave.  Final rows, fp32 scores and the Stage-1 rows (ids and score bits) of a fuzzy batch must be
-    identical, with deletions too.  (Until round 6 this test also held the alternative accumulation designs — mask scatter, probe-pool-score, 4-bit cells,
+    1 / 2 / 8 doc ranges per wave.  Likewise k_select's cut, whether a query's rows are swept by its own workgroup or by several in front of it (k_selg_*).
+    Final rows, fp32 scores and the Stage-1 rows (ids and score bits) of a fuzzy batch must be identical, with deletions too.  (Until round 6 this test also held the alternative accumulation designs — mask scatter, probe-pool-score, 4-bit cells,
     container mailbox, and round 6's search kernel; all bit-identical, none faster, all deleted: HISTORY.md.)"""
     import os
     import subprocess
@@ -591,7 +591,9 @@ np.savez(sys.argv[1], **out)
     res = []
     variants = [dict(),                                                        # shipping split: stripes of <= 64 candidates search, the rest stream
                 dict(INFX_ACC_SPARSE_T="0"), dict(INFX_ACC_SPARSE_T="8"), dict(INFX_ACC_SPARSE_T="33"), dict(INFX_ACC_SPARSE_T="150"), dict(INFX_ACC_SPARSE_T="4096"),      # one kernel (streaming) / other split points (beyond 64: several rounds per stripe)
-                dict(INFX_ACC_SPARSE_T="0", INFX_ACC_SKIP="32"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="1"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="2"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="8")]
+                dict(INFX_ACC_SPARSE_T="0", INFX_ACC_SKIP="32"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="1"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="2"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="8"),
+                # k_select: the largest queries swept by several workgroups (k_selg_hist / k_selg_gather) from 64 / 3000 rows on (default 65536: none at this size), or never
+                dict(INFX_SEL_GIANT_MIN="64"), dict(INFX_SEL_GIANT_MIN="3000"), dict(INFX_SEL_GIANT_MIN="0")]
     for vi, var in enumerate(variants):
         env = dict(os.environ); env.update(var)
         env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

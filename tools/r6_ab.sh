@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; TAG=$1; shift
 for v in "$@"; do
   lib=$R/infidex_amd/libinfidex_hip.so; [ "$v" != base ] && lib=$R/infidex_amd/libinfidex_hip_$v.so
   echo "== $v"
-  INFX_LIB=$lib bash $R/tools/r6_kt.sh ${TAG}_$v -- --steps 12 --warmup 3 --long-steps 0 --no-cpu-baseline $BARGS | grep "k_accumulate"
+  INFX_LIB=$lib bash $R/tools/r6_kt.sh ${TAG}_$v -- --steps 12 --warmup 3 --long-steps 0 --no-cpu-baseline $BARGS | grep "${KGREP:-k_accumulate}"
   python - $R/gpurun_out/${TAG}_$v/kt.json <<'PY'
 import json,sys
 try:
