@@ -554,6 +554,25 @@ static const uint32_t* select_order(infx_stream* s, uint32_t nq) {
     k_select_order<<<1, 1024, 0, s->st>>>((const uint32_t*)s->dBlockOutHi, nq, (uint32_t*)s->dSelOrder);
     return (const uint32_t*)s->dSelOrder;
 }
+#ifdef SEL_PROF
+// profiling build only: per-workgroup wall_clock64() stamps (8 words per workgroup: t0 .. t5, two free words) -> span of the launch, the longest workgroups, percentiles
+static void wgprof_dump(const char* name, const unsigned long long* dProf, uint32_t n, const char* const ph[5], hipStream_t st) {
+    hipStreamSynchronize(st);
+    std::vector<unsigned long long> h((size_t)n * 8); hipMemcpy(h.data(), dProf, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t5 = 0; for (uint32_t q = 0; q < n; q++) if (h[q * 8]) { t0 = std::min(t0, h[q * 8]); for (int k = 1; k < 6; k++) t5 = std::max(t5, h[q * 8 + k]); }
+    fprintf(stderr, "[%s] span %.1f us\n", name, (t5 - t0) / 100.0);
+    auto endOf = [&](uint32_t q) { unsigned long long e = h[q * 8]; for (int k = 1; k < 6; k++) e = std::max(e, h[q * 8 + k]); return e; };
+    std::vector<uint32_t> ord(n); for (uint32_t q = 0; q < n; q++) ord[q] = q;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return endOf(a) - h[a * 8] > endOf(b) - h[b * 8]; });
+    auto us = [&](uint32_t q, int a, int b) { const unsigned long long x = h[q * 8 + a], y = h[q * 8 + b]; return (x && y) ? (double)(y - x) / 100.0 : -1.0; };
+    auto line = [&](const char* tag, uint32_t q) { fprintf(stderr, "[%s] %s wg %u w6 %llu w7 %llu: start %.1f total %.1f | %s %.1f %s %.1f %s %.1f %s %.1f %s %.1f\n", name, tag, q, h[q * 8 + 6], h[q * 8 + 7], (h[q * 8] - t0) / 100.0,
+                                                        (endOf(q) - h[q * 8]) / 100.0, ph[0], us(q, 0, 1), ph[1], us(q, 1, 2), ph[2], us(q, 2, 3), ph[3], us(q, 3, 4), ph[4], us(q, 4, 5)); };
+    for (int i = 0; i < 10 && i < (int)n; i++) line("top", ord[i]);
+    line("p50", ord[n / 2]); line("p90", ord[n / 10]); line("p99", ord[n / 100]);
+    std::vector<unsigned long long> en(n); for (uint32_t q = 0; q < n; q++) en[q] = endOf(q) - t0; std::sort(en.begin(), en.end());
+    fprintf(stderr, "[%s] ends: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us\n", name, en[n / 10] / 100.0, en[n / 2] / 100.0, en[n * 9 / 10] / 100.0, en[n * 99 / 100] / 100.0, en[n - 1] / 100.0);
+}
+#endif
 // The largest queries of the batch swept by many workgroups in front of k_select (k_selg_hist / k_selg_gather, stage1.hip.inc).  INFX_SEL_GIANT_MIN: rows from which a
 // query is one (default 65536; 0: off — k_select sweeps every query itself).  Needs the longest-first order (its first SELG_MAX entries are the candidates).
 static SelGiant select_giants(infx_stream* s, Arena ar, uint32_t nq, const uint32_t* order) {
@@ -1545,21 +1564,7 @@ static int32_t fused_enqueue_select(infx_stream* s, uint32_t nd, int32_t depth, 
         k_select<<<nd, SEL_THREADS, 0, s->st>>>(ar, ix->d.nRanges, (const SelRule*)s->dRules, (infx_hit*)s->dHits, (uint32_t*)s->dHitCount, depth, exact ? (uint32_t*)s->dExactFlag : nullptr, exact ? s->dExactStat + 4 : nullptr,
                                                 shardNext ? (float*)s->dNext : nullptr, selOrd, selG);
 #ifdef SEL_PROF
-        if (dProf && nd >= 500 && ++profCalls == 6) {
-            hipStreamSynchronize(s->st);
-            std::vector<unsigned long long> h((size_t)nd * 8); hipMemcpy(h.data(), dProf, h.size() * 8, hipMemcpyDeviceToHost);
-            unsigned long long t0 = ~0ull, t5 = 0; for (uint32_t q = 0; q < nd; q++) { t0 = std::min(t0, h[q * 8]); t5 = std::max(t5, h[q * 8 + 5]); }
-            fprintf(stderr, "[selprof] span %.1f us (100 MHz ticks)\n", (t5 - t0) / 100.0);
-            std::vector<uint32_t> ord(nd); for (uint32_t q = 0; q < nd; q++) ord[q] = q;
-            std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return h[a * 8 + 5] - h[a * 8] > h[b * 8 + 5] - h[b * 8]; });
-            auto us = [&](uint32_t q, int a, int b) { const unsigned long long x = h[q * 8 + a], y = h[q * 8 + b]; return (x && y) ? (double)(y - x) / 100.0 : -1.0; };
-            for (int i = 0; i < 12; i++) { const uint32_t q = ord[i]; fprintf(stderr, "[selprof] #%d q %u rows %llu n %llu: start %.1f total %.1f | hist1 %.1f hist2 %.1f gather %.1f sort %.1f write %.1f (0->3 %.1f)\n", i, q, h[q * 8 + 6], h[q * 8 + 7], (h[q * 8] - t0) / 100.0, us(q, 0, 5), us(q, 0, 1), us(q, 1, 2), us(q, 2, 3), us(q, 3, 4), us(q, 4, 5), us(q, 0, 3)); }
-            for (int pct : {50, 90, 99}) { const uint32_t q = ord[(size_t)nd * (100 - pct) / 100]; fprintf(stderr, "[selprof] p%d q %u rows %llu n %llu: start %.1f total %.1f | hist1 %.1f hist2 %.1f gather %.1f sort %.1f write %.1f (0->3 %.1f)\n", pct, q, h[q * 8 + 6], h[q * 8 + 7], (h[q * 8] - t0) / 100.0, us(q, 0, 5), us(q, 0, 1), us(q, 1, 2), us(q, 2, 3), us(q, 3, 4), us(q, 4, 5), us(q, 0, 3)); }
-            std::vector<unsigned long long> st(nd), en(nd); for (uint32_t q = 0; q < nd; q++) { st[q] = h[q * 8] - t0; en[q] = h[q * 8 + 5] - t0; }
-            std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
-            fprintf(stderr, "[selprof] starts: p10 %.1f p50 %.1f p90 %.1f max %.1f us; ends: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us\n", st[nd / 10] / 100.0, st[nd / 2] / 100.0, st[nd * 9 / 10] / 100.0, st[nd - 1] / 100.0,
-                    en[nd / 10] / 100.0, en[nd / 2] / 100.0, en[nd * 9 / 10] / 100.0, en[nd * 99 / 100] / 100.0, en[nd - 1] / 100.0);
-        }
+        if (dProf && nd >= 500 && ++profCalls == 6) { static const char* const ph[5] = {"hist1", "hist2", "gather", "sort", "write"}; wgprof_dump("selprof", dProf, nd, ph, s->st); }
 #endif
         if (markTurn) { HIPCHK(hipEventRecord(s->evTurn, s->st)); markTurn = false; }      // the wide phase of this batch ends here (round 6 measured the event in FRONT of k_select — the next batch's accumulation beside this k_select's tail of giant queries: 93.7 / 94.2 k against 93.8 / 94.3 k queries/s, nothing)
         if (exact) { int32_t rc_ = mark_wide_queries(s, ix->cfg.max_depth); if (rc_) return rc_; }
@@ -1621,9 +1626,16 @@ static int32_t fused_enqueue_prep_stage2(infx_stream* s, int W, uint32_t nd, con
         const size_t Pp = std::max<size_t>(Dp, P2_CAP);
         const size_t lds = (size_t)Dp * 4 * 4 + Pp * 4 + (size_t)P2_CAP * 4 + (size_t)Dp * 8 + (size_t)Dp * 2 + Pp + (size_t)P2_MAXLISTS * (8 + 4 + 4 + 4) + (P2_THREADS + 2) * 4 + (size_t)Dall * 8 + 64;
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifdef SEL_PROF
+        static unsigned long long* dP2 = nullptr; static int p2Calls = 0;
+        if (getenv("INFX_SEL_PROF") && nq >= 500) { if (!dP2) { hipMalloc((void**)&dP2, 4096 * 64); hipMemcpyToSymbol(HIP_SYMBOL(g_p2Prof), &dP2, sizeof(dP2)); } hipMemsetAsync(dP2, 0, (size_t)nq * 64, s->st); }
+#endif
         k_prep2<<<nq, P2_THREADS, lds, s->st>>>(ix->d, dHitsAll, dHcAll, depth, W, (int)nd, (int)Dall, (const infx_fused_query*)s->dFQ,
                                                  (const infx_wm_list*)s->dFLists, (const int32_t*)s->dFOwned, depth, (int)Dp,
                                                  (infx_hit*)s->dFS1, (infx_cov_cand*)s->dCovC, (int32_t*)s->dFPairs, (FusedMeta*)s->dFMeta);
+#ifdef SEL_PROF
+        if (dP2 && nq >= 500 && ++p2Calls == 6) { static const char* const ph[5] = {"s1sort", "topsort", "overlap", "wmrounds", "emit"}; wgprof_dump("p2prof", dP2, nq, ph, s->st); }
+#endif
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->evP1, s->st));
