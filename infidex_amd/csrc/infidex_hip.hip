@@ -293,9 +293,10 @@ struct infx_stream {
     uint32_t* arExc = nullptr; uint32_t* exCand = nullptr; infx_hit* exOut = nullptr; size_t exCap = 0;       // tf exception records, candidate lists, replay rows (arena-sized)
     void* exChunks = nullptr; size_t capExChunks = 0; void* exQueries = nullptr; size_t capExQueries = 0; void* exTasks = nullptr; size_t capExTasks = 0; uint32_t* exCounters = nullptr;
     void* dSelOrder = nullptr; size_t capSelOrder = 0;        // k_select_order: the batch's queries by row count, descending
+    void* dAccOrder = nullptr; size_t capAccOrder = 0; uint32_t nAccHeavy = 0xFFFFFFFFu;      // k_accumulate: the batch's queries by row bound, descending, and how many of them go first (~0: query order)
     void* dSelG = nullptr; size_t capSelG = 0;                // k_selg_hist / k_selg_gather: global histograms, key lists and flags of the batch's largest queries
     void* exContEnd = nullptr; size_t capExContEnd = 0;      // k_ex_cand: candidates up to the end of every (query, container)
-    uint32_t exChunkCap = 0; size_t arBound = 0;
+    uint32_t exChunkCap = 0; size_t arBound = 0; unsigned long long maxQueryBound = 0;
     void* dDir = nullptr; size_t capDir = 0;
     void* dRefTerms = nullptr; size_t capRefTerms = 0; void* dExactFlag = nullptr; size_t capExactFlag = 0; uint32_t* dExactStat = nullptr;   // k_exact1 inputs
     uint32_t lastExact2[2] = {0, 0};                                                     // last batch: queries replayed exactly, of them by the sequential fallback                                            // (query, range) chunk directory
@@ -539,7 +540,8 @@ template <int R> static void launch_acc(infx_stream* s, uint32_t nq, Arena ar, i
     }
     const size_t lds = (size_t)R + 128 + ((size_t)(R / 32) + 2) * 4 + INFX_NCLASS * 4 + ACC_CAP_DEFAULT * 2;
 #define ACC_LAUNCH(MW_) k_accumulate<R, MW_><<<dim3((unsigned)blocks), dim3(WAVE), lds, s->st>>>(s->ix->d, (const DevQuery*)s->dQueries, (const DevTerm*)s->dTerms, (const int32_t*)s->dExtra, \
-        (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nStripes)
+        (const int32_t*)s->dUDocs, (const uint32_t*)s->dURange, nq, ar, maxT, stripe, useGrp, dbgSkip, (unsigned long long*)s->dStats, dense, nStripes, \
+        s->nAccHeavy != 0xFFFFFFFFu ? (const uint32_t*)s->dAccOrder : nullptr, s->nAccHeavy != 0xFFFFFFFFu ? s->nAccHeavy : 0u)
     if (ar.maskWords == 4) ACC_LAUNCH(4); else if (ar.maskWords == 2) ACC_LAUNCH(2); else ACC_LAUNCH(1);
 #undef ACC_LAUNCH
     if (dbgSkip & 8) { unsigned long long h[4] = {0, 0, 0, 0}; hipStreamSynchronize(s->st); hipMemcpy(h, s->dStats, 32, hipMemcpyDeviceToHost); hipMemset(s->dStats, 0, 32);
@@ -577,7 +579,7 @@ static void wgprof_dump(const char* name, const unsigned long long* dProf, uint3
 // query is one (default 65536; 0: off — k_select sweeps every query itself).  Needs the longest-first order (its first SELG_MAX entries are the candidates).
 static SelGiant select_giants(infx_stream* s, Arena ar, uint32_t nq, const uint32_t* order) {
     static const uint32_t minRows = [] { const char* e = getenv("INFX_SEL_GIANT_MIN"); return e ? (uint32_t)std::max(0, atoi(e)) : 65536u; }();
-    SelGiant G{}; if (!order || !minRows) return G;
+    SelGiant G{}; if (!order || !minRows || s->maxQueryBound < minRows) return G;
     const size_t head = (size_t)SELG_MAX * 2 * 4096 * 4 + (size_t)SELG_MAX * 4 * 5, total = head + (size_t)SELG_MAX * SEL_CAP * 8;
     if (grow(s, &s->dSelG, &s->capSelG, total)) return G;
     hipMemsetAsync(s->dSelG, 0, head, s->st);
@@ -1067,7 +1069,7 @@ void infx_stream_destroy(infx_stream* s) {
     void* ps[] = {s->dQueries, s->dTerms, s->dExtra, s->dRules, s->dHits, s->dHitCount, s->dBlockOut, s->dBlockOutHi, s->dQBytes, s->dUOffs, s->dUMem, s->dUCnt, s->dURange, s->dUBase, s->dUDocs, s->dCounts,
                   s->dCovQ, s->dCovC, s->dCovO, s->dCovF, s->arDoc, s->arScore, s->arCls, s->dCursor, s->dOverflow,
                   s->dFQ, s->dFLists, s->dFOwned, s->dFS1, s->dFMeta, s->dFQueries, s->dFKeys, s->dFScores, s->dFTies, s->dFCounts, s->dFFlags, s->dFErr, s->dFHitsAll, s->dFHcAll, s->dFPairs, s->arMask, s->dDir, s->dFDocs, s->dFacetCols, s->dFacCodes, s->dFacCounts, s->dFacN, s->dRefTerms, s->dExactFlag, s->dExactStat, s->arExc, s->exCand, s->exOut, s->exChunks, s->exQueries, s->exTasks, s->exCounters, s->exContEnd, s->dExProf, s->dSelOrder,
-                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount, s->dDense, s->dSelG};
+                  s->dNext, s->dPrior, s->shBlob, s->dAllBlobs, s->dAllNext, s->dChainState, s->dChainNeed, s->dHugeWs, s->dHugeCnt, s->dLWordOff, s->dLChars, s->dLMembers, s->dLCount, s->dDense, s->dSelG, s->dAccOrder};
     for (void* p : ps) if (p) hipFree(p);
     for (void* p : s->scratch) if (p) hipFree(p);
     for (void* p : s->parked) hipFree(p);
@@ -1099,7 +1101,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
     std::vector<int32_t> termOfEntry; termOfEntry.reserve(nterms + 64);
     std::vector<DevRefTerm> refT(std::max<uint32_t>(1, nterms));
     for (uint32_t k = 0; k < nterms; k++) refT[k] = DevRefTerm{terms[k].idf, terms[k].max_score, terms[k].term_id, terms[k].term_id < 0 ? 1u : 0u};
-    std::vector<unsigned long long> qbase((size_t)nq + 1);
+    std::vector<unsigned long long> qbase((size_t)nq + 1); unsigned long long maxQb = 0;
     unsigned long long bound = 0; int maxT = 1, useGrp = 0, maxRef = 0, maxRefNarrow = 0; std::vector<uint32_t> wideQ;
     for (uint32_t i = 0; i < nq; i++) {
         const infx_query& Q = q[i];
@@ -1151,8 +1153,21 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
         if (Q.mode == INFX_MODE_PREFIX) qb = ix->hPsOff[Q.prefix_set + 1] - ix->hPsOff[Q.prefix_set];
         qbase[i] = bound;
         bound += std::min<unsigned long long>(qb, (unsigned long long)ix->d.N);
+        maxQb = std::max(maxQb, std::min<unsigned long long>(qb, (unsigned long long)ix->d.N));
     }
     qbase[nq] = bound;
+    {   // k_accumulate's block order: queries by row bound, descending; "heavy" = at least INFX_ACC_HEAVY_ROWS (default 393216) candidate rows possible, at most 64 queries
+        static const long long heavyRows = [] { const char* e = getenv("INFX_ACC_HEAVY_ROWS"); return e ? atoll(e) : 393216ll; }();      // 0: query order
+        s->nAccHeavy = 0xFFFFFFFFu;
+        if (heavyRows > 0 && nq > 1) {
+            std::vector<uint32_t> ord(nq); for (uint32_t i = 0; i < nq; i++) ord[i] = i;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return qbase[a + 1] - qbase[a] > qbase[b + 1] - qbase[b]; });
+            uint32_t h = 0; while (h < nq - 1 && h < 64u && qbase[ord[h] + 1] - qbase[ord[h]] >= (unsigned long long)heavyRows) h++;
+            GROW(s->dAccOrder, s->capAccOrder, (size_t)nq * 4); UP(s->dAccOrder, ord.data(), (size_t)nq * 4);
+            s->nAccHeavy = h;
+        }
+    }
+    s->maxQueryBound = maxQb;      // no query of the batch can hold more rows than this (select_giants: nothing to sweep outside k_select below its threshold)
     {   // INFX_ACC_SHARE_STATS=1 (profiling): how many posting bytes do the queries of the batch share?  total = sum over (query, list) of the list length;
         // distinct = every list once; by XCD = every list once per XCD under the current block -> XCD assignment (q % 8) and under a chunked assignment of
         // the queries sorted by their longest list

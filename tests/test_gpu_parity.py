@@ -593,7 +593,9 @@ np.savez(sys.argv[1], **out)
                 dict(INFX_ACC_SPARSE_T="0"), dict(INFX_ACC_SPARSE_T="8"), dict(INFX_ACC_SPARSE_T="33"), dict(INFX_ACC_SPARSE_T="150"), dict(INFX_ACC_SPARSE_T="4096"),      # one kernel (streaming) / other split points (beyond 64: several rounds per stripe)
                 dict(INFX_ACC_SPARSE_T="0", INFX_ACC_SKIP="32"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="1"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="2"), dict(INFX_ACC_SPARSE_T="0", INFX_ACC_STRIPE="8"),
                 # k_select: the largest queries swept by several workgroups (k_selg_hist / k_selg_gather) from 64 / 3000 rows on (default 65536: none at this size), or never
-                dict(INFX_SEL_GIANT_MIN="64"), dict(INFX_SEL_GIANT_MIN="3000"), dict(INFX_SEL_GIANT_MIN="0")]
+                dict(INFX_SEL_GIANT_MIN="64"), dict(INFX_SEL_GIANT_MIN="3000"), dict(INFX_SEL_GIANT_MIN="0"),
+                # k_accumulate's block order: the (up to 64) queries of >= 2000 / 20000 possible rows take all their stripes first, or plain query order (default 393216 rows: none at this size, queries by row bound)
+                dict(INFX_ACC_HEAVY_ROWS="2000"), dict(INFX_ACC_HEAVY_ROWS="20000", INFX_ACC_SPARSE_T="0"), dict(INFX_ACC_HEAVY_ROWS="0")]
     for vi, var in enumerate(variants):
         env = dict(os.environ); env.update(var)
         env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
