@@ -41,7 +41,7 @@ def kernel_sha16():
     h = hashlib.sha256(open(os.path.join(csrc, "stage1.hip.inc"), "rb").read())
     h.update(open(os.path.join(csrc, "stage1_sparse.hip.inc"), "rb").read())
     src = open(os.path.join(csrc, "infidex_hip.hip")).read()
-    a = src.index("template <int R> static void launch_acc("); b = src.index("// k_exact1 behind k_select", a)
+    a = src.index("template <int R> static void launch_acc("); b = src.index("// Longest-queries-first order for k_select", a)
     h.update(src[a:b].encode())
     return h.hexdigest()[:16]
 

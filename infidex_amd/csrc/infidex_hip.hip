@@ -294,6 +294,7 @@ struct infx_stream {
     void* exChunks = nullptr; size_t capExChunks = 0; void* exQueries = nullptr; size_t capExQueries = 0; void* exTasks = nullptr; size_t capExTasks = 0; uint32_t* exCounters = nullptr;
     void* dSelOrder = nullptr; size_t capSelOrder = 0;        // k_select_order: the batch's queries by row count, descending
     void* dAccOrder = nullptr; size_t capAccOrder = 0; uint32_t nAccHeavy = 0xFFFFFFFFu;      // k_accumulate: the batch's queries by row bound, descending, and how many of them go first (~0: query order)
+    uint32_t nBoundGiants = 0;                               // queries of the batch whose row bound reaches k_select's multi-workgroup threshold
     void* dSelG = nullptr; size_t capSelG = 0;                // k_selg_hist / k_selg_gather: global histograms, key lists and flags of the batch's largest queries
     void* exContEnd = nullptr; size_t capExContEnd = 0;      // k_ex_cand: candidates up to the end of every (query, container)
     uint32_t exChunkCap = 0; size_t arBound = 0; unsigned long long maxQueryBound = 0;
@@ -577,15 +578,19 @@ static void wgprof_dump(const char* name, const unsigned long long* dProf, uint3
 #endif
 // The largest queries of the batch swept by many workgroups in front of k_select (k_selg_hist / k_selg_gather, stage1.hip.inc).  INFX_SEL_GIANT_MIN: rows from which a
 // query is one (default 65536; 0: off — k_select sweeps every query itself).  Needs the longest-first order (its first SELG_MAX entries are the candidates).
+static uint32_t giant_min_rows() { static const uint32_t v = [] { const char* e = getenv("INFX_SEL_GIANT_MIN"); return e ? (uint32_t)std::max(0, atoi(e)) : 65536u; }(); return v; }
 static SelGiant select_giants(infx_stream* s, Arena ar, uint32_t nq, const uint32_t* order) {
-    static const uint32_t minRows = [] { const char* e = getenv("INFX_SEL_GIANT_MIN"); return e ? (uint32_t)std::max(0, atoi(e)) : 65536u; }();
-    SelGiant G{}; if (!order || !minRows || s->maxQueryBound < minRows) return G;
+    const uint32_t minRows = giant_min_rows();
+    SelGiant G{}; if (!order || !minRows || !s->nBoundGiants || s->maxQueryBound < 4ull * minRows) return G;      // (three launches + two memsets cost ~50 us: not for a batch whose largest query k_select sweeps in that time)
     const size_t head = (size_t)SELG_MAX * 2 * 4096 * 4 + (size_t)SELG_MAX * 4 * 5, total = head + (size_t)SELG_MAX * SEL_CAP * 8;
     if (grow(s, &s->dSelG, &s->capSelG, total)) return G;
-    hipMemsetAsync(s->dSelG, 0, head, s->st);
+    const uint32_t nSlots = std::min<uint32_t>(SELG_MAX, std::min(nq, s->nBoundGiants));
+    hipMemsetAsync(s->dSelG, 0, (size_t)nSlots * 2 * 4096 * 4, s->st);                                             // the histograms of the slots in use
+    hipMemsetAsync((char*)s->dSelG + (size_t)SELG_MAX * 2 * 4096 * 4, 0, (size_t)SELG_MAX * 4 * 5, s->st);       // count | left | mode | cut | shift
     G.hist = (uint32_t*)s->dSelG; G.count = G.hist + (size_t)SELG_MAX * 2 * 4096; G.left = G.count + SELG_MAX; G.mode = G.left + SELG_MAX; G.cut = G.mode + SELG_MAX; G.shift = G.cut + SELG_MAX;
     G.keys = (unsigned long long*)((char*)s->dSelG + head); G.minRows = minRows;
-    const dim3 grid(SELG_PARTS, std::min<uint32_t>(SELG_MAX, nq));
+    // (a query holds at most its row bound: the slots and partitions that can be needed are known on the host — a batch of small queries launches a handful of workgroups)
+    const dim3 grid((unsigned)std::min<uint64_t>(SELG_PARTS, (s->maxQueryBound + SELG_PART_MIN - 1) / SELG_PART_MIN), nSlots);
     k_selg_hist<<<grid, SEL_THREADS, 0, s->st>>>(ar, (const SelRule*)s->dRules, order, nq, G);
     k_selg_cut<<<grid.y, 256, 0, s->st>>>(ar, (const SelRule*)s->dRules, order, nq, G);
     k_selg_gather<<<grid, SEL_THREADS, 0, s->st>>>(ar, (const SelRule*)s->dRules, order, nq, G);
@@ -1167,6 +1172,7 @@ static int32_t acc_enqueue(infx_stream* s, uint32_t nq, const infx_query* q, uin
             s->nAccHeavy = h;
         }
     }
+    { const unsigned long long gm = giant_min_rows(); uint32_t c = 0; if (gm) for (uint32_t i = 0; i < nq; i++) if (qbase[i + 1] - qbase[i] >= gm) c++; s->nBoundGiants = c; }
     s->maxQueryBound = maxQb;      // no query of the batch can hold more rows than this (select_giants: nothing to sweep outside k_select below its threshold)
     {   // INFX_ACC_SHARE_STATS=1 (profiling): how many posting bytes do the queries of the batch share?  total = sum over (query, list) of the list length;
         // distinct = every list once; by XCD = every list once per XCD under the current block -> XCD assignment (q % 8) and under a chunked assignment of
