@@ -56,7 +56,7 @@ def roofline_by_kernel(roof):
     nq = m("queries") or 1000.0
     spec = [
         # kernel, duration key, algorithmic bytes, bound, what the bytes are
-        ("k_select", "k_select_ms", rows * 9.0, "latency", "arena rows x (class 1 B + score 4 B + doc id 4 B), each read once (the radix select reads class + score once per pass: 2-3 passes)"),
+        ("k_select", "k_select_ms", rows * 9.0, "latency", "arena rows x (class 1 B + score 4 B + doc id 4 B), each read once (the radix select reads class + score once per pass: 2-3 passes); incl. k_select_order and the multi-workgroup sweeps of the largest queries (k_selg_*)"),
         ("k_ex_scan", "k_ex_scan_ms", m("replay_rows") * 12.0, "serial-latency", "k_ex_walk x2 + k_ex_prefix + k_ex_theta: rows of the flagged queries x (class 1 B + score 4 B + directory / candidate-list 7 B); the time is k_ex_theta's ~1 400 serial sorted insertions per query on one wave"),
         ("k_ex_chunk", "k_ex_chunk_ms", m("replay_rows") * (4.0 + 8.0 + 4.0 + 4.0), "latency", "k_ex_chunk<1|4|16>: candidate rows of the flagged queries x (list entry 4 B + hit mask 8 B + tf exceptions 4 B + doc length 4 B); three dependent loads + the term loop per chunk task"),
         ("k_ex_heap", "k_ex_heap_ms", m("replay_rows") * 8.0, "serial-latency", "emitted candidates x (doc 4 B + score 4 B); time = ~2 k dependent 4-ary heap operations per query on one wave (register-resident heap: ~1 200 cycles each)"),
@@ -430,8 +430,9 @@ def main():
                                "stream, timed as one span)", "bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS, "traffic": None,
                      "limiter": "not bandwidth: the accumulation is priced against the HBM roofline (byte streaming, no MFMA work) by SURVEY 8(d)'s algorithmic bytes, but the streaming "
-                                "kernel (dense stripes: ~4.0 ms) is bound by VALU / SALU issue and latency of its (posting list, doc range) visits, and the sparse kernel (stripes of <= 96 "
-                                "candidates: ~2.0 ms) by the latency of its dependent lookups - it does not stream its lists at all (profiles/r06_final_10m.md, r06_pmc.json)",
+                                "kernel (dense stripes: ~3.7 ms with all 4096 wave slots busy since its blocks run heaviest query first) is bound by VALU / SALU issue and latency of its (posting list, "
+                                "doc range) visits, and the sparse kernel (stripes of <= 96 candidates: ~2.0 ms) by the lane-loads of its dependent lookups - it does not stream its lists at "
+                                "all (profiles/r06_final_10m.md, r06_accumulate_blocks.md, r06_pmc.json)",
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": acc_ms,
                      "streamed_bytes_per_launch": streamed, "stage1_candidates_per_launch": float(np.mean([t["stage1_candidates"] for t in roof])),
                      "stage2_rows_per_launch": float(np.mean([t["stage2_candidates"] for t in roof])), "exact_replays_per_launch": float(np.mean([t["exact_replays"] for t in roof])), "streamed_GBps": streamed / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
