@@ -1286,7 +1286,14 @@ int32_t infx_stage1_accumulate(infx_stream* s, uint32_t nq, const infx_query* q,
     if (nq == 0) return INFX_OK;
     HIPCHK(enter_device(ix->cfg.device));
     { int32_t rc_ = pin_reset(s); if (rc_) return rc_; }
-    { int32_t rc_ = acc_enqueue(s, nq, q, nterms, terms, extra_n, extra_docs); if (rc_) return rc_; }
+    {   // the turnstile of infx_search_fused for the staged (document-sharded) pipeline: a batch's accumulation waits, stream-side, for the accumulation of the batch
+        // submitted before it on this index — the pipeline sessions of a rank take the GPU-filling kernel one after the other instead of against each other
+        static const bool turnstile = [] { const char* e = getenv("INFX_TURNSTILE"); return !(e && e[0] == '0'); }();
+        std::unique_lock<std::mutex> turn(ix->turnMu, std::defer_lock);
+        if (turnstile) { turn.lock(); if (ix->turnEvent && ix->turnEvent != s->evTurn) HIPCHK(hipStreamWaitEvent(s->st, ix->turnEvent, 0)); }
+        { int32_t rc_ = acc_enqueue(s, nq, q, nterms, terms, extra_n, extra_docs); if (rc_) return rc_; }
+        if (turnstile) { HIPCHK(hipEventRecord(s->evTurn, s->st)); ix->turnEvent = s->evTurn; }
+    }
     uint32_t ovf = 0; std::vector<unsigned long long> qbytes(nq);
     if (counts_out) DOWNX(counts_out, s->dCounts, (size_t)nq * INFX_NCLASS * 4);       // host memory, or a device tensor the caller all-reduces in place
     DOWN(&ovf, s->dOverflow, 4);
