@@ -90,7 +90,7 @@ def main():
     # round 4 (workspaces never reallocated mid-stream, turnstile on the wide phase; 100 steps, queries/s and p50 / p95 batch latency ms): 3: 67.7 k, 42 / 56;
     # 4: 72.7 k, 52 / 75; 5: 74.6 k, 63 / 88; 6: 73.7-77.1 k, 75 / 111; 8: 74.0 k, 97 / 169 — five keeps the rate of six at 15 % less latency
     ap.add_argument("--sessions", type=int, default=4, help="batches in flight (host threads, one engine session each)")
-    ap.add_argument("--shard-sessions", type=int, default=3, help="sharded runs: batches in flight per rank (pipeline sessions, each with its own stream and communicator)")
+    ap.add_argument("--shard-sessions", type=int, default=4, help="sharded runs: batches in flight per rank (pipeline sessions, each with its own stream and communicator); W = 1 forced-sharded, 40 steps: 3: 81.5 k, 4: 87.8 k, 5: 92.3 k, 6: 85.8 k queries/s")
     ap.add_argument("--distinct-batches", type=int, default=0, help="distinct synthetic query batches the steps cycle through; 0 (default) = warmup + steps, "
                     "i.e. no batch — and so no misspelt word beyond what the Zipf stream itself repeats — occurs twice: planning is measured cold")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent full-index replicas instead of document shards")
